@@ -1,0 +1,975 @@
+/*
+ * rnd_abi.cpp -- host side of the C ABI declared in include/renderer_amd.h.
+ *
+ * Owns device memory, records command buffers, and turns a recorded pass into
+ * the kernel sequence of rnd_kernels.hip.  There is no CPU rendering path: if a
+ * HIP call fails the entry point fails.
+ */
+#include "../../include/renderer_amd.h"
+#include "rnd_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace rnd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? RND_ERROR_OUT_OF_DEVICE_MEMORY : RND_ERROR_DEVICE_LOST, \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+double srgb_to_linear(double s) { return s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4); }
+
+template <typename T>
+struct DeviceArray {
+    T* ptr = nullptr;
+    size_t count = 0;
+    hipError_t resize(size_t n)
+    {
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
+        count = n;
+        if (!n) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        hipError_t e = resize(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } count = 0; }
+};
+
+} // namespace
+
+struct rnd_device_t {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* srgb_decode = nullptr;
+    float* srgb_thr = nullptr;
+    uint8_t* srgb_lut = nullptr;
+    bool profiling = false;
+    hipEvent_t ev[RND_STAGE_COUNT + 1] = {};
+    float stage_ms[RND_STAGE_COUNT] = {};
+    bool stage_valid = false;
+};
+
+struct rnd_buffer_t {
+    rnd_device dev;
+    uint8_t* ptr;
+    uint64_t bytes;
+    uint32_t usage;
+};
+
+struct rnd_texture_t {
+    rnd_device dev;
+    uint32_t width, height, levels;
+    uint32_t srgb;
+    rnd_sampler_info sampler;
+    uint8_t* level_ptr[16];
+};
+
+struct rnd_target_t {
+    rnd_device dev;
+    uint32_t width, height, samples;
+    int32_t color_format;
+    uint8_t* color;
+    uint32_t* depth;
+};
+
+struct rnd_pipeline_t {
+    rnd_device dev;
+    rnd_pipeline_info info;
+};
+
+struct rnd_fence_t {
+    rnd_device dev;
+    hipEvent_t ev;
+    bool pending;
+};
+
+namespace {
+
+struct RecordedDraw {
+    rnd_pipeline pipeline;
+    rnd_buffer vb; uint64_t vb_offset;
+    rnd_buffer ib; uint64_t ib_offset;
+    rnd_buffer ubo; uint64_t ubo_offset;
+    rnd_texture tex;
+    float push[32];
+    uint32_t index_count, first_index;
+    int32_t vertex_offset;
+};
+
+enum CmdState { CMD_INITIAL, CMD_RECORDING, CMD_IN_PASS, CMD_EXECUTABLE };
+
+} // namespace
+
+struct rnd_cmd_t {
+    rnd_device dev = nullptr;
+    CmdState state = CMD_INITIAL;
+    /* pass */
+    bool has_pass = false;
+    rnd_target target = nullptr;
+    float clear_color[4] = {0, 0, 0, 0};
+    float clear_depth = 1.0f;
+    int32_t area[4] = {0, 0, 0, 0};
+    bool has_viewport = false, has_scissor = false;
+    float viewport[6] = {0, 0, 0, 0, 0, 1};
+    int32_t scissor[4] = {0, 0, 0, 0};
+    /* bindings while recording */
+    rnd_pipeline cur_pipeline = nullptr;
+    rnd_buffer cur_vb = nullptr; uint64_t cur_vb_offset = 0;
+    rnd_buffer cur_ib = nullptr; uint64_t cur_ib_offset = 0;
+    rnd_buffer cur_ubo = nullptr; uint64_t cur_ubo_offset = 0;
+    rnd_texture cur_tex = nullptr;
+    float cur_push[32] = {};
+    std::vector<RecordedDraw> draws;
+    /* compiled */
+    DeviceArray<DrawStatic> d_draws;
+    DeviceArray<DrawDerived> d_derived;
+    DeviceArray<Chunk> d_vchunks, d_tchunks;
+    DeviceArray<TexDesc> d_textures;
+    DeviceArray<SVtx> d_svtx;
+    DeviceArray<uint32_t> d_prim_bbox, d_tile_count, d_tile_offset, d_tile_cursor, d_refs, d_large_list, d_large_count;
+    FrameParams fp = {};
+    uint32_t shard_index = 0, shard_count = 1;
+
+    void release_compiled()
+    {
+        d_draws.release(); d_derived.release(); d_vchunks.release(); d_tchunks.release(); d_textures.release();
+        d_svtx.release(); d_prim_bbox.release(); d_tile_count.release(); d_tile_offset.release(); d_tile_cursor.release();
+        d_refs.release(); d_large_list.release(); d_large_count.release();
+    }
+};
+
+namespace {
+
+int set_device(rnd_device dev)
+{
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    return RND_SUCCESS;
+}
+
+bool format_is_srgb(int32_t f)
+{
+    return f == RND_FORMAT_R8_SRGB || f == RND_FORMAT_R8G8_SRGB || f == RND_FORMAT_R8G8B8_SRGB || f == RND_FORMAT_R8G8B8A8_SRGB ||
+           f == RND_FORMAT_B8G8R8A8_SRGB;
+}
+
+/* channels of a texel format, 0 when unsupported (tools.cpp:469-512) */
+int format_channels(int32_t f)
+{
+    switch (f) {
+    case RND_FORMAT_R8_UNORM: case RND_FORMAT_R8_UINT: case RND_FORMAT_R8_SRGB: return 1;
+    case RND_FORMAT_R8G8_UNORM: case RND_FORMAT_R8G8_UINT: case RND_FORMAT_R8G8_SRGB: return 2;
+    case RND_FORMAT_R8G8B8_UNORM: case RND_FORMAT_R8G8B8_UINT: case RND_FORMAT_R8G8B8_SRGB: return 3;
+    case RND_FORMAT_R8G8B8A8_UNORM: case RND_FORMAT_R8G8B8A8_UINT: case RND_FORMAT_R8G8B8A8_SRGB: return 4;
+    default: return 0;
+    }
+}
+
+/* Expand to RGBA8 with the component mapping of the reference's image views
+ * (tools.cpp:474-509): R -> (r,r,r,1), RG -> (r,0,0,g), RGB -> (r,g,b,1). */
+void expand_rgba(const uint8_t* src, int ch, size_t texels, std::vector<uint8_t>& out)
+{
+    out.resize(texels * 4);
+    for (size_t i = 0; i < texels; ++i) {
+        const uint8_t* p = src + i * (size_t)ch;
+        uint8_t* o = &out[i * 4];
+        switch (ch) {
+        case 1: o[0] = p[0]; o[1] = p[0]; o[2] = p[0]; o[3] = 255; break;
+        case 2: o[0] = p[0]; o[1] = 0; o[2] = 0; o[3] = p[1]; break;
+        case 3: o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 255; break;
+        default: o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; break;
+        }
+    }
+}
+
+uint32_t level_dim(uint32_t d, uint32_t l) { uint32_t v = d >> l; return v ? v : 1u; }
+
+uint32_t host_depth24(float z)
+{
+    z = fminf(fmaxf(z, 0.0f), 1.0f);
+    float t = fmaf(z, 16777215.0f, 0.5f);
+    uint32_t d = (uint32_t)t;
+    return d > 0xFFFFFFu ? 0xFFFFFFu : d;
+}
+
+int texture_alloc(rnd_device dev, uint32_t w, uint32_t h, int32_t format, uint32_t levels, const rnd_sampler_info* sampler,
+                  rnd_texture* out)
+{
+    if (!w || !h || w > 16384 || h > 16384) return fail(RND_ERROR_INVALID_ARGUMENT, "texture extent out of range");
+    if (levels < 1 || levels > 16) return fail(RND_ERROR_INVALID_ARGUMENT, "texture level count out of range");
+    rnd_texture t = new rnd_texture_t();
+    t->dev = dev; t->width = w; t->height = h; t->levels = levels; t->srgb = format_is_srgb(format) ? 1u : 0u;
+    t->sampler = sampler ? *sampler : rnd_sampler_info{RND_FILTER_LINEAR, 0, 0.0f};
+    memset(t->level_ptr, 0, sizeof(t->level_ptr));
+    for (uint32_t l = 0; l < levels; ++l) {
+        size_t bytes = (size_t)level_dim(w, l) * level_dim(h, l) * 4;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->level_ptr[l]), bytes);
+        if (e != hipSuccess) {
+            for (uint32_t k = 0; k < l; ++k) (void)hipFree(t->level_ptr[k]);
+            delete t;
+            return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc texture level failed");
+        }
+    }
+    *out = t;
+    return RND_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rnd_last_error(void) { return g_last_error.c_str(); }
+
+/* ------------------------------------------------------------------ device */
+
+int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
+{
+    if (!out) return fail(RND_ERROR_INVALID_ARGUMENT, "rnd_device_create: out is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RND_ERROR_INITIALIZATION_FAILED, "no HIP device is visible");
+    if (hip_ordinal < 0 || hip_ordinal >= n) return fail(RND_ERROR_INVALID_ARGUMENT, "HIP device ordinal out of range");
+    HIP_TRY(hipSetDevice(hip_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, hip_ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RND_ERROR_INITIALIZATION_FAILED, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    rnd_device dev = new rnd_device_t();
+    dev->ordinal = hip_ordinal;
+    if (stream) { dev->stream = static_cast<hipStream_t>(stream); dev->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete dev; return fail(RND_ERROR_DEVICE_LOST, "hipStreamCreate failed"); }
+        dev->own_stream = true;
+    }
+    /* sRGB tables: decode[k] = linear value of code k; thr[k] = linear value of code k-0.5;
+     * lut[bucket] = number of thresholds <= the bucket's lower edge */
+    std::vector<float> decode(256), thr(257);
+    std::vector<uint8_t> lut(SRGB_LUT_SIZE);
+    for (int k = 0; k < 256; ++k) decode[(size_t)k] = (float)srgb_to_linear(k / 255.0);
+    thr[0] = -INFINITY;
+    for (int k = 1; k < 256; ++k) thr[(size_t)k] = (float)srgb_to_linear((k - 0.5) / 255.0);
+    thr[256] = INFINITY;
+    for (uint32_t i = 0; i < SRGB_LUT_SIZE; ++i) {
+        uint32_t bits = (i + SRGB_LUT_FIRST) << 16;
+        float c;
+        memcpy(&c, &bits, 4);
+        uint32_t k = 0;
+        while (k < 255 && thr[k + 1] <= c) ++k;
+        lut[i] = (uint8_t)k;
+    }
+    hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&dev->srgb_decode), 256 * 4);
+    hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&dev->srgb_thr), 257 * 4);
+    hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&dev->srgb_lut), SRGB_LUT_SIZE);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { rnd_device_destroy(dev); return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc tables failed"); }
+    HIP_TRY(hipMemcpy(dev->srgb_decode, decode.data(), 256 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev->srgb_thr, thr.data(), 257 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev->srgb_lut, lut.data(), SRGB_LUT_SIZE, hipMemcpyHostToDevice));
+    for (int i = 0; i <= RND_STAGE_COUNT; ++i) HIP_TRY(hipEventCreate(&dev->ev[i]));
+    *out = dev;
+    return RND_SUCCESS;
+}
+
+int rnd_device_destroy(rnd_device dev)
+{
+    if (!dev) return RND_SUCCESS;
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamSynchronize(dev->stream);
+    if (dev->srgb_decode) (void)hipFree(dev->srgb_decode);
+    if (dev->srgb_thr) (void)hipFree(dev->srgb_thr);
+    if (dev->srgb_lut) (void)hipFree(dev->srgb_lut);
+    for (int i = 0; i <= RND_STAGE_COUNT; ++i) if (dev->ev[i]) (void)hipEventDestroy(dev->ev[i]);
+    if (dev->own_stream && dev->stream) (void)hipStreamDestroy(dev->stream);
+    delete dev;
+    return RND_SUCCESS;
+}
+
+int rnd_device_wait_idle(rnd_device dev)
+{
+    if (!dev) return fail(RND_ERROR_INVALID_ARGUMENT, "device is null");
+    if (int r = set_device(dev)) return r;
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    return RND_SUCCESS;
+}
+
+void* rnd_device_stream(rnd_device dev) { return dev ? static_cast<void*>(dev->stream) : nullptr; }
+
+int rnd_device_set_profiling(rnd_device dev, int enable)
+{
+    if (!dev) return fail(RND_ERROR_INVALID_ARGUMENT, "device is null");
+    dev->profiling = enable != 0;
+    dev->stage_valid = false;
+    return RND_SUCCESS;
+}
+
+int rnd_device_stage_times(rnd_device dev, float* ms, int count)
+{
+    if (!dev || !ms || count < RND_STAGE_COUNT) return fail(RND_ERROR_INVALID_ARGUMENT, "stage_times: bad arguments");
+    if (!dev->stage_valid) return fail(RND_ERROR_INVALID_ARGUMENT, "no profiled submit has completed");
+    if (int r = set_device(dev)) return r;
+    HIP_TRY(hipEventSynchronize(dev->ev[RND_STAGE_COUNT]));
+    for (int i = 0; i < RND_STAGE_COUNT; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], dev->ev[i], dev->ev[i + 1]));
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ buffers */
+
+int rnd_buffer_create(rnd_device dev, uint64_t bytes, uint32_t usage, const void* init, rnd_buffer* out)
+{
+    if (!dev || !out || !bytes) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_create: bad arguments");
+    if (int r = set_device(dev)) return r;
+    uint8_t* p = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), (size_t)bytes));
+    if (init) {
+        hipError_t e = hipMemcpy(p, init, (size_t)bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); return fail(RND_ERROR_DEVICE_LOST, "buffer upload failed"); }
+    }
+    rnd_buffer b = new rnd_buffer_t{dev, p, bytes, usage};
+    *out = b;
+    return RND_SUCCESS;
+}
+
+int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t bytes)
+{
+    if (!buf || !src) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write: bad arguments");
+    if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write: range outside the buffer");
+    if (int r = set_device(buf->dev)) return r;
+    /* stream-ordered after earlier submits; the host memory is consumed before return (pageable copy) */
+    HIP_TRY(hipMemcpyAsync(buf->ptr + offset, src, (size_t)bytes, hipMemcpyHostToDevice, buf->dev->stream));
+    HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+    return RND_SUCCESS;
+}
+
+int rnd_buffer_write_device(rnd_buffer buf, uint64_t offset, const void* device_src, uint64_t bytes)
+{
+    if (!buf || !device_src) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write_device: bad arguments");
+    if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write_device: range outside the buffer");
+    if (int r = set_device(buf->dev)) return r;
+    HIP_TRY(hipMemcpyAsync(buf->ptr + offset, device_src, (size_t)bytes, hipMemcpyDeviceToDevice, buf->dev->stream));
+    return RND_SUCCESS;
+}
+
+int rnd_buffer_read(rnd_buffer buf, uint64_t offset, void* dst, uint64_t bytes)
+{
+    if (!buf || !dst) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_read: bad arguments");
+    if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_read: range outside the buffer");
+    if (int r = set_device(buf->dev)) return r;
+    HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+    HIP_TRY(hipMemcpy(dst, buf->ptr + offset, (size_t)bytes, hipMemcpyDeviceToHost));
+    return RND_SUCCESS;
+}
+
+int rnd_buffer_destroy(rnd_buffer buf)
+{
+    if (!buf) return RND_SUCCESS;
+    (void)hipSetDevice(buf->dev->ordinal);
+    (void)hipStreamSynchronize(buf->dev->stream);
+    (void)hipFree(buf->ptr);
+    delete buf;
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ textures */
+
+int rnd_texture_create_2d(rnd_device dev, uint32_t width, uint32_t height, int32_t format, int32_t gen_mips,
+                          const void* texels, const rnd_sampler_info* sampler, rnd_texture* out)
+{
+    if (!dev || !out || !texels) return fail(RND_ERROR_INVALID_ARGUMENT, "texture_create_2d: bad arguments");
+    int ch = format_channels(format);
+    if (!ch) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "unsupported pixels format."); /* tools.cpp:511 */
+    if (int r = set_device(dev)) return r;
+    /* tools.cpp:514: mip_levels = (uint32_t)log2(max(w,h)) -- one short of a full chain */
+    uint32_t levels = 1;
+    if (gen_mips) {
+        levels = (uint32_t)log2((double)(width > height ? width : height));
+        if (levels < 1) levels = 1;
+    }
+    rnd_texture t = nullptr;
+    if (int r = texture_alloc(dev, width, height, format, levels, sampler, &t)) return r;
+    std::vector<uint8_t> rgba;
+    const uint8_t* src = static_cast<const uint8_t*>(texels);
+    if (ch != 4) { expand_rgba(src, ch, (size_t)width * height, rgba); src = rgba.data(); }
+    hipError_t e = hipMemcpy(t->level_ptr[0], src, (size_t)width * height * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rnd_texture_destroy(t); return fail(RND_ERROR_DEVICE_LOST, "texture upload failed"); }
+    for (uint32_t l = 1; l < levels; ++l) {
+        launch_mip(t->level_ptr[l - 1], level_dim(width, l - 1), level_dim(height, l - 1), t->level_ptr[l], level_dim(width, l),
+                   level_dim(height, l), (int)t->srgb, dev->srgb_decode, dev->srgb_thr, dev->srgb_lut, dev->stream);
+    }
+    e = hipStreamSynchronize(dev->stream); /* the reference waits on a fence here (tools.cpp:776-778) */
+    if (e != hipSuccess) { rnd_texture_destroy(t); return fail(RND_ERROR_DEVICE_LOST, std::string("mip generation failed: ") + hipGetErrorString(e)); }
+    *out = t;
+    return RND_SUCCESS;
+}
+
+int rnd_texture_create_levels(rnd_device dev, uint32_t width, uint32_t height, int32_t format, uint32_t level_count,
+                              const void* const* level_texels, const rnd_sampler_info* sampler, rnd_texture* out)
+{
+    if (!dev || !out || !level_texels) return fail(RND_ERROR_INVALID_ARGUMENT, "texture_create_levels: bad arguments");
+    int ch = format_channels(format);
+    if (!ch) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "unsupported pixels format.");
+    if (int r = set_device(dev)) return r;
+    rnd_texture t = nullptr;
+    if (int r = texture_alloc(dev, width, height, format, level_count, sampler, &t)) return r;
+    for (uint32_t l = 0; l < level_count; ++l) {
+        size_t texels = (size_t)level_dim(width, l) * level_dim(height, l);
+        std::vector<uint8_t> rgba;
+        const uint8_t* src = static_cast<const uint8_t*>(level_texels[l]);
+        if (!src) { rnd_texture_destroy(t); return fail(RND_ERROR_INVALID_ARGUMENT, "texture level pointer is null"); }
+        if (ch != 4) { expand_rgba(src, ch, texels, rgba); src = rgba.data(); }
+        hipError_t e = hipMemcpy(t->level_ptr[l], src, texels * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rnd_texture_destroy(t); return fail(RND_ERROR_DEVICE_LOST, "texture upload failed"); }
+    }
+    *out = t;
+    return RND_SUCCESS;
+}
+
+int rnd_texture_level_count(rnd_texture tex, uint32_t* out)
+{
+    if (!tex || !out) return fail(RND_ERROR_INVALID_ARGUMENT, "texture_level_count: bad arguments");
+    *out = tex->levels;
+    return RND_SUCCESS;
+}
+
+int rnd_texture_read_level(rnd_texture tex, uint32_t level, void* rgba8_out)
+{
+    if (!tex || !rgba8_out || level >= tex->levels) return fail(RND_ERROR_INVALID_ARGUMENT, "texture_read_level: bad arguments");
+    if (int r = set_device(tex->dev)) return r;
+    HIP_TRY(hipStreamSynchronize(tex->dev->stream));
+    HIP_TRY(hipMemcpy(rgba8_out, tex->level_ptr[level], (size_t)level_dim(tex->width, level) * level_dim(tex->height, level) * 4,
+                      hipMemcpyDeviceToHost));
+    return RND_SUCCESS;
+}
+
+int rnd_texture_destroy(rnd_texture tex)
+{
+    if (!tex) return RND_SUCCESS;
+    (void)hipSetDevice(tex->dev->ordinal);
+    (void)hipStreamSynchronize(tex->dev->stream);
+    for (uint32_t l = 0; l < 16; ++l) if (tex->level_ptr[l]) (void)hipFree(tex->level_ptr[l]);
+    delete tex;
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ targets */
+
+int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t color_format, int32_t depth_format,
+                      uint32_t samples, rnd_target* out)
+{
+    if (!dev || !out) return fail(RND_ERROR_INVALID_ARGUMENT, "target_create: bad arguments");
+    if (!width || !height || width > TILE_W * MAX_TILE_AXIS || height > TILE_H * MAX_TILE_AXIS)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "target extent must be 1..8192 in each dimension");
+    if (color_format != RND_FORMAT_R8G8B8A8_SRGB && color_format != RND_FORMAT_B8G8R8A8_SRGB &&
+        color_format != RND_FORMAT_R8G8B8A8_UNORM && color_format != RND_FORMAT_B8G8R8A8_UNORM)
+        return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "colour format must be R8G8B8A8 or B8G8R8A8, UNORM or SRGB");
+    if (depth_format != RND_FORMAT_D24_UNORM_S8_UINT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "depth format must be D24_UNORM_S8_UINT");
+    if (samples != 1 && samples != 4) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "sample count must be 1 or 4");
+    if (int r = set_device(dev)) return r;
+    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr};
+    size_t px = (size_t)width * height;
+    hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&t->color), px * 4);
+    hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&t->depth), px * samples * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess) { rnd_target_destroy(t); return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc target failed"); }
+    (void)hipMemset(t->color, 0, px * 4);
+    (void)hipMemset(t->depth, 0, px * samples * 4);
+    *out = t;
+    return RND_SUCCESS;
+}
+
+int rnd_target_read(rnd_target target, void* color_out, uint32_t* depth_out)
+{
+    if (!target) return fail(RND_ERROR_INVALID_ARGUMENT, "target_read: target is null");
+    if (int r = set_device(target->dev)) return r;
+    HIP_TRY(hipStreamSynchronize(target->dev->stream));
+    size_t px = (size_t)target->width * target->height;
+    if (color_out) HIP_TRY(hipMemcpy(color_out, target->color, px * 4, hipMemcpyDeviceToHost));
+    if (depth_out) HIP_TRY(hipMemcpy(depth_out, target->depth, px * target->samples * 4, hipMemcpyDeviceToHost));
+    return RND_SUCCESS;
+}
+
+void* rnd_target_color_device_ptr(rnd_target target) { return target ? target->color : nullptr; }
+
+int rnd_target_destroy(rnd_target target)
+{
+    if (!target) return RND_SUCCESS;
+    (void)hipSetDevice(target->dev->ordinal);
+    (void)hipStreamSynchronize(target->dev->stream);
+    if (target->color) (void)hipFree(target->color);
+    if (target->depth) (void)hipFree(target->depth);
+    delete target;
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ pipelines */
+
+int rnd_pipeline_create(rnd_device dev, const rnd_pipeline_info* info, rnd_pipeline* out)
+{
+    if (!dev || !info || !out) return fail(RND_ERROR_INVALID_ARGUMENT, "pipeline_create: bad arguments");
+    if (info->shader < RND_SHADER_DUMMY || info->shader > RND_SHADER_PUSH_CONSTANTS) return fail(RND_ERROR_INVALID_ARGUMENT, "unknown shader id");
+    if (info->topology != RND_TOPOLOGY_TRIANGLE_LIST) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "only TRIANGLE_LIST is supported");
+    if (info->position.format != RND_FORMAT_R32G32B32_SFLOAT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "position must be R32G32B32_SFLOAT");
+    if (info->normal.format != 0 && info->normal.format != RND_FORMAT_R32G32B32_SFLOAT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "normal must be R32G32B32_SFLOAT");
+    if (info->uv.format != 0 && info->uv.format != RND_FORMAT_R32G32_SFLOAT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "uv must be R32G32_SFLOAT");
+    if (!info->stride || (info->stride & 3u) || (info->position.offset & 3u) || (info->normal.offset & 3u) || (info->uv.offset & 3u))
+        return fail(RND_ERROR_INVALID_ARGUMENT, "vertex stride and attribute offsets must be multiples of 4");
+    if (info->position.offset + 12 > info->stride || (info->normal.format && info->normal.offset + 12 > info->stride) ||
+        (info->uv.format && info->uv.offset + 8 > info->stride))
+        return fail(RND_ERROR_INVALID_ARGUMENT, "vertex attribute reaches past the stride");
+    if (info->cull_mode < 0 || info->cull_mode > 3 || info->front_face < 0 || info->front_face > 1) return fail(RND_ERROR_INVALID_ARGUMENT, "bad cull state");
+    if (info->depth_test) {
+        if (info->depth_compare != RND_COMPARE_LESS && info->depth_compare != RND_COMPARE_LESS_OR_EQUAL)
+            return fail(RND_ERROR_FEATURE_NOT_PRESENT, "depth compare must be LESS or LESS_OR_EQUAL");
+        if (!info->depth_write) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "depth test without depth write is not supported");
+    }
+    if (info->samples != 1 && info->samples != 4) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "sample count must be 1 or 4");
+    if (info->color_write_mask != 0xFu) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "colour write mask must be RGBA");
+    if (info->blend_enable) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "blending is not supported");
+    *out = new rnd_pipeline_t{dev, *info};
+    return RND_SUCCESS;
+}
+
+int rnd_pipeline_destroy(rnd_pipeline p)
+{
+    delete p;
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ command recording */
+
+int rnd_cmd_create(rnd_device dev, rnd_cmd* out)
+{
+    if (!dev || !out) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd_create: bad arguments");
+    rnd_cmd c = new rnd_cmd_t();
+    c->dev = dev;
+    *out = c;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_begin(rnd_cmd cmd)
+{
+    if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd is null");
+    if (cmd->state == CMD_RECORDING || cmd->state == CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "command buffer is already recording");
+    if (int r = set_device(cmd->dev)) return r;
+    (void)hipStreamSynchronize(cmd->dev->stream);
+    cmd->release_compiled();
+    cmd->draws.clear();
+    cmd->has_pass = false; cmd->has_viewport = false; cmd->has_scissor = false;
+    cmd->cur_pipeline = nullptr; cmd->cur_vb = nullptr; cmd->cur_ib = nullptr; cmd->cur_ubo = nullptr; cmd->cur_tex = nullptr;
+    memset(cmd->cur_push, 0, sizeof(cmd->cur_push));
+    cmd->state = CMD_RECORDING;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_begin_pass(rnd_cmd cmd, rnd_target target, const float clear_color[4], float clear_depth,
+                       int32_t area_x, int32_t area_y, uint32_t area_w, uint32_t area_h)
+{
+    if (!cmd || !target || !clear_color) return fail(RND_ERROR_INVALID_ARGUMENT, "begin_pass: bad arguments");
+    if (cmd->state != CMD_RECORDING) return fail(RND_ERROR_RECORDING, "begin_pass outside recording state");
+    if (cmd->has_pass) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "one render pass per command buffer");
+    if (target->dev != cmd->dev) return fail(RND_ERROR_INVALID_ARGUMENT, "target belongs to another device");
+    if (area_x < 0 || area_y < 0 || (uint64_t)area_x + area_w > target->width || (uint64_t)area_y + area_h > target->height)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "render area outside the target");
+    cmd->target = target;
+    memcpy(cmd->clear_color, clear_color, 16);
+    cmd->clear_depth = clear_depth;
+    cmd->area[0] = area_x; cmd->area[1] = area_y; cmd->area[2] = (int32_t)area_w; cmd->area[3] = (int32_t)area_h;
+    cmd->has_pass = true;
+    cmd->state = CMD_IN_PASS;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_set_viewport(rnd_cmd cmd, float x, float y, float w, float h, float min_depth, float max_depth)
+{
+    if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd is null");
+    if (cmd->state != CMD_IN_PASS && cmd->state != CMD_RECORDING) return fail(RND_ERROR_RECORDING, "set_viewport outside recording state");
+    if (!cmd->draws.empty()) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "one viewport per pass: set it before the first draw");
+    if (!(w > 0.0f) || !(h > 0.0f) || !(min_depth >= 0.0f && min_depth <= 1.0f) || !(max_depth >= 0.0f && max_depth <= 1.0f))
+        return fail(RND_ERROR_INVALID_ARGUMENT, "viewport extent or depth range invalid");
+    /* window coordinates are held in 24.8 with the outcode in the low byte of x: the
+     * guard band (2x the half extent) must stay inside +-32767 pixels */
+    if (!(fabsf(x + 0.5f * w) + w + 1.0f < 32767.0f) || !(fabsf(y + 0.5f * h) + h + 1.0f < 32767.0f))
+        return fail(RND_ERROR_FEATURE_NOT_PRESENT, "viewport too large or too far from the origin");
+    cmd->viewport[0] = x; cmd->viewport[1] = y; cmd->viewport[2] = w; cmd->viewport[3] = h; cmd->viewport[4] = min_depth; cmd->viewport[5] = max_depth;
+    cmd->has_viewport = true;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_set_scissor(rnd_cmd cmd, int32_t x, int32_t y, uint32_t w, uint32_t h)
+{
+    if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd is null");
+    if (cmd->state != CMD_IN_PASS && cmd->state != CMD_RECORDING) return fail(RND_ERROR_RECORDING, "set_scissor outside recording state");
+    if (!cmd->draws.empty()) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "one scissor per pass: set it before the first draw");
+    if (x < 0 || y < 0 || w > 0x7FFFFFFFu || h > 0x7FFFFFFFu) return fail(RND_ERROR_INVALID_ARGUMENT, "scissor offset must be non-negative");
+    cmd->scissor[0] = x; cmd->scissor[1] = y; cmd->scissor[2] = (int32_t)w; cmd->scissor[3] = (int32_t)h;
+    cmd->has_scissor = true;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_bind_pipeline(rnd_cmd cmd, rnd_pipeline p)
+{
+    if (!cmd || !p) return fail(RND_ERROR_INVALID_ARGUMENT, "bind_pipeline: bad arguments");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "bind_pipeline outside a render pass");
+    cmd->cur_pipeline = p;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_bind_vertex_buffer(rnd_cmd cmd, rnd_buffer buf, uint64_t byte_offset)
+{
+    if (!cmd || !buf) return fail(RND_ERROR_INVALID_ARGUMENT, "bind_vertex_buffer: bad arguments");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "bind_vertex_buffer outside a render pass");
+    if (byte_offset > buf->bytes || (byte_offset & 3u)) return fail(RND_ERROR_INVALID_ARGUMENT, "vertex buffer offset outside the buffer or not a multiple of 4");
+    cmd->cur_vb = buf; cmd->cur_vb_offset = byte_offset;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_bind_index_buffer(rnd_cmd cmd, rnd_buffer buf, uint64_t byte_offset, int32_t index_type)
+{
+    if (!cmd || !buf) return fail(RND_ERROR_INVALID_ARGUMENT, "bind_index_buffer: bad arguments");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "bind_index_buffer outside a render pass");
+    if (index_type != RND_INDEX_TYPE_UINT32) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "index type must be UINT32");
+    if (byte_offset > buf->bytes || (byte_offset & 3u)) return fail(RND_ERROR_INVALID_ARGUMENT, "index buffer offset outside the buffer or not a multiple of 4");
+    cmd->cur_ib = buf; cmd->cur_ib_offset = byte_offset;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_bind_uniform(rnd_cmd cmd, uint32_t set, uint32_t binding, rnd_buffer buf, uint64_t offset, uint64_t range)
+{
+    if (!cmd || !buf) return fail(RND_ERROR_INVALID_ARGUMENT, "bind_uniform: bad arguments");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "bind_uniform outside a render pass");
+    if (set != 0 || binding != 0) return fail(RND_ERROR_INVALID_ARGUMENT, "the uniform block is set 0 binding 0");
+    if ((offset & 3u) || range < 320 || offset > buf->bytes || buf->bytes - offset < 320)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "the uniform block needs 320 bytes (five mat4)");
+    cmd->cur_ubo = buf; cmd->cur_ubo_offset = offset;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_bind_texture(rnd_cmd cmd, uint32_t set, uint32_t binding, rnd_texture tex)
+{
+    if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "bind_texture: bad arguments");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "bind_texture outside a render pass");
+    if (!((set == 0 && binding == 1) || (set == 1 && binding == 0))) return fail(RND_ERROR_INVALID_ARGUMENT, "the sampler is set 0 binding 1 or set 1 binding 0");
+    cmd->cur_tex = tex;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_push_constants(rnd_cmd cmd, uint32_t offset, uint32_t size, const void* data)
+{
+    if (!cmd || !data) return fail(RND_ERROR_INVALID_ARGUMENT, "push_constants: bad arguments");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "push_constants outside a render pass");
+    if ((offset & 3u) || (size & 3u) || offset + size > 128) return fail(RND_ERROR_INVALID_ARGUMENT, "push constant range must lie in 0..128 and be 4-byte aligned");
+    memcpy(reinterpret_cast<uint8_t*>(cmd->cur_push) + offset, data, size);
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_draw_indexed(rnd_cmd cmd, uint32_t index_count, uint32_t instance_count, uint32_t first_index,
+                         int32_t vertex_offset, uint32_t first_instance)
+{
+    (void)first_instance;
+    if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd is null");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "draw_indexed outside a render pass");
+    if (!cmd->cur_pipeline || !cmd->cur_vb || !cmd->cur_ib || !cmd->cur_ubo) return fail(RND_ERROR_RECORDING, "draw_indexed needs a pipeline, vertex, index and uniform buffer bound");
+    if (vertex_offset < 0) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "negative vertexOffset is not supported");
+    if (instance_count == 0 || index_count < 3) return RND_SUCCESS;
+    /* the shaders never read gl_InstanceIndex: every instance draws the same fragments, so one is recorded */
+    uint64_t ib_avail = (cmd->cur_ib->bytes - cmd->cur_ib_offset) / 4;
+    if ((uint64_t)first_index + index_count > ib_avail) return fail(RND_ERROR_INVALID_ARGUMENT, "draw reads past the index buffer");
+    RecordedDraw d;
+    d.pipeline = cmd->cur_pipeline;
+    d.vb = cmd->cur_vb; d.vb_offset = cmd->cur_vb_offset;
+    d.ib = cmd->cur_ib; d.ib_offset = cmd->cur_ib_offset;
+    d.ubo = cmd->cur_ubo; d.ubo_offset = cmd->cur_ubo_offset;
+    d.tex = cmd->cur_tex;
+    memcpy(d.push, cmd->cur_push, sizeof(d.push));
+    d.index_count = index_count; d.first_index = first_index; d.vertex_offset = vertex_offset;
+    cmd->draws.push_back(d);
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_end_pass(rnd_cmd cmd)
+{
+    if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd is null");
+    if (cmd->state != CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "end_pass outside a render pass");
+    cmd->state = CMD_RECORDING;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_set_tile_shard(rnd_cmd cmd, uint32_t shard_index, uint32_t shard_count)
+{
+    if (!cmd || !shard_count || shard_index >= shard_count) return fail(RND_ERROR_INVALID_ARGUMENT, "set_tile_shard: bad arguments");
+    cmd->shard_index = shard_index; cmd->shard_count = shard_count;
+    return RND_SUCCESS;
+}
+
+/* Turns the recorded draws into device tables.  Runs once per recording, like the
+ * reference's record_command_buffers (recorded once, submitted every frame). */
+int rnd_cmd_end(rnd_cmd cmd)
+{
+    if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd is null");
+    if (cmd->state != CMD_RECORDING) return fail(RND_ERROR_RECORDING, "cmd_end outside recording state (pass still open?)");
+    if (!cmd->has_pass) return fail(RND_ERROR_RECORDING, "command buffer holds no render pass");
+    if (!cmd->draws.empty() && (!cmd->has_viewport || !cmd->has_scissor)) return fail(RND_ERROR_RECORDING, "viewport and scissor are dynamic state: set both");
+    rnd_device dev = cmd->dev;
+    rnd_target tg = cmd->target;
+    if (int r = set_device(dev)) return r;
+
+    /* depth state is one per pass (all pipelines of the samples share it) */
+    int depth_test = 1, depth_less = 0;
+    for (size_t i = 0; i < cmd->draws.size(); ++i) {
+        const rnd_pipeline_info& pi = cmd->draws[i].pipeline->info;
+        if (pi.samples != tg->samples) return fail(RND_ERROR_INVALID_ARGUMENT, "pipeline sample count differs from the target's");
+        int dt = pi.depth_test ? 1 : 0, dl = (pi.depth_test && pi.depth_compare == RND_COMPARE_LESS) ? 1 : 0;
+        if (i == 0) { depth_test = dt; depth_less = dl; }
+        else if (dt != depth_test || dl != depth_less) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "all pipelines of a pass must share the depth state");
+    }
+
+    const size_t n = cmd->draws.size();
+    std::vector<DrawStatic> ds(n);
+    std::vector<rnd_texture> tex_list;
+    std::vector<IndexRangeJob> jobs;
+    std::vector<uint32_t> job_of(n);
+    std::map<std::pair<const uint32_t*, uint32_t>, uint32_t> job_map;
+    for (size_t i = 0; i < n; ++i) {
+        const RecordedDraw& rd = cmd->draws[i];
+        const rnd_pipeline_info& pi = rd.pipeline->info;
+        DrawStatic& d = ds[i];
+        memset(&d, 0, sizeof(d));
+        uint64_t vb_first = rd.vb_offset + (uint64_t)rd.vertex_offset * pi.stride;
+        uint64_t vb_avail = vb_first <= rd.vb->bytes ? rd.vb->bytes - vb_first : 0;
+        d.vb = rd.vb->ptr + (vb_first <= rd.vb->bytes ? vb_first : 0);
+        uint64_t cap = vb_avail / pi.stride;
+        d.vb_capacity = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+        d.ib = reinterpret_cast<const uint32_t*>(rd.ib->ptr + rd.ib_offset) + rd.first_index;
+        d.ubo = reinterpret_cast<const float*>(rd.ubo->ptr + rd.ubo_offset);
+        d.stride = pi.stride;
+        d.off_pos = (int32_t)pi.position.offset;
+        d.off_nrm = pi.normal.format ? (int32_t)pi.normal.offset : -1;
+        d.off_uv = pi.uv.format ? (int32_t)pi.uv.offset : -1;
+        d.tri_count = rd.index_count / 3;
+        d.shader = pi.shader;
+        d.cull_mode = (uint32_t)pi.cull_mode;
+        d.front_face = (uint32_t)pi.front_face;
+        memcpy(d.push, rd.push, sizeof(d.push));
+        d.texture = -1;
+        if (rd.tex) {
+            size_t k = 0;
+            while (k < tex_list.size() && tex_list[k] != rd.tex) ++k;
+            if (k == tex_list.size()) tex_list.push_back(rd.tex);
+            d.texture = (int32_t)k;
+        }
+        auto key = std::make_pair(d.ib, d.tri_count * 3);
+        auto it = job_map.find(key);
+        if (it == job_map.end()) {
+            it = job_map.emplace(key, (uint32_t)jobs.size()).first;
+            jobs.push_back(IndexRangeJob{d.ib, d.tri_count * 3, 0});
+        }
+        job_of[i] = it->second;
+    }
+
+    /* how many vertices each draw references: largest index + 1, bounded by the buffer */
+    std::vector<uint32_t> job_max(jobs.size(), 0);
+    if (!jobs.empty()) {
+        DeviceArray<IndexRangeJob> d_jobs;
+        DeviceArray<uint32_t> d_max;
+        HIP_TRY(d_jobs.upload(jobs));
+        HIP_TRY(d_max.resize(jobs.size()));
+        HIP_TRY(hipMemsetAsync(d_max.ptr, 0, jobs.size() * 4, dev->stream));
+        for (size_t b = 0; b < jobs.size(); b += 32768) {
+            uint32_t cnt = (uint32_t)std::min<size_t>(32768, jobs.size() - b);
+            launch_index_range(d_jobs.ptr + b, d_max.ptr + b, cnt, dev->stream);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        HIP_TRY(hipMemcpy(job_max.data(), d_max.ptr, jobs.size() * 4, hipMemcpyDeviceToHost));
+        d_jobs.release(); d_max.release();
+    }
+
+    std::vector<Chunk> vchunks, tchunks;
+    uint64_t svtx_total = 0, prim_total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        DrawStatic& d = ds[i];
+        uint64_t want = (uint64_t)job_max[job_of[i]] + 1;
+        d.vert_count = d.tri_count ? (uint32_t)std::min<uint64_t>(want, d.vb_capacity) : 0;
+        if (svtx_total + d.vert_count > 0xFFFFFFFFull) return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "pass references more than 2^32 vertices");
+        d.svtx_base = (uint32_t)svtx_total;
+        svtx_total += d.vert_count;
+        d.prim_base = (uint32_t)prim_total;
+        prim_total += d.tri_count;
+        for (uint32_t v = 0; v < d.vert_count; v += CHUNK) vchunks.push_back(Chunk{(uint32_t)i, v});
+        for (uint32_t t = 0; t < d.tri_count; t += CHUNK) tchunks.push_back(Chunk{(uint32_t)i, t});
+    }
+    if (tchunks.size() >= (1u << 26)) return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "pass holds more than 2^32 primitive slots");
+
+    std::vector<TexDesc> td(tex_list.size());
+    for (size_t k = 0; k < tex_list.size(); ++k) {
+        rnd_texture t = tex_list[k];
+        memset(&td[k], 0, sizeof(TexDesc));
+        for (uint32_t l = 0; l < t->levels; ++l) td[k].level[l] = t->level_ptr[l];
+        td[k].width = t->width; td[k].height = t->height; td[k].levels = t->levels;
+        td[k].srgb = t->srgb; td[k].tiled = t->sampler.tiled ? 1u : 0u;
+        td[k].filter_linear = t->sampler.filtering == RND_FILTER_NEAREST ? 0u : 1u;
+    }
+
+    const uint32_t tiles_x = (tg->width + TILE_W - 1) / TILE_W, tiles_y = (tg->height + TILE_H - 1) / TILE_H;
+    const size_t n_tiles = (size_t)tiles_x * tiles_y;
+    const size_t slots = tchunks.size() * CHUNK;
+    const size_t per_prim = std::min<size_t>(MAX_TILES_PER_PRIM, n_tiles);
+
+    cmd->release_compiled();
+    HIP_TRY(cmd->d_draws.upload(ds));
+    HIP_TRY(cmd->d_derived.resize(n));
+    HIP_TRY(cmd->d_vchunks.upload(vchunks));
+    HIP_TRY(cmd->d_tchunks.upload(tchunks));
+    HIP_TRY(cmd->d_textures.upload(td));
+    HIP_TRY(cmd->d_svtx.resize((size_t)svtx_total));
+    HIP_TRY(cmd->d_prim_bbox.resize(slots));
+    HIP_TRY(cmd->d_tile_count.resize(n_tiles));
+    HIP_TRY(cmd->d_tile_offset.resize(n_tiles));
+    HIP_TRY(cmd->d_tile_cursor.resize(n_tiles));
+    HIP_TRY(cmd->d_refs.resize(slots * per_prim));
+    HIP_TRY(cmd->d_large_list.resize(slots));
+    HIP_TRY(cmd->d_large_count.resize(1));
+
+    FrameParams& fp = cmd->fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.draws = cmd->d_draws.ptr; fp.derived = cmd->d_derived.ptr;
+    fp.vchunks = cmd->d_vchunks.ptr; fp.tchunks = cmd->d_tchunks.ptr; fp.textures = cmd->d_textures.ptr;
+    fp.svtx = cmd->d_svtx.ptr; fp.prim_bbox = cmd->d_prim_bbox.ptr;
+    fp.tile_count = cmd->d_tile_count.ptr; fp.tile_offset = cmd->d_tile_offset.ptr; fp.tile_cursor = cmd->d_tile_cursor.ptr;
+    fp.refs = cmd->d_refs.ptr; fp.large_list = cmd->d_large_list.ptr; fp.large_count = cmd->d_large_count.ptr;
+    fp.color = tg->color; fp.depth = tg->depth;
+    fp.srgb_decode = dev->srgb_decode; fp.srgb_thr = dev->srgb_thr; fp.srgb_lut = dev->srgb_lut;
+    fp.n_draws = (uint32_t)n; fp.n_vchunks = (uint32_t)vchunks.size(); fp.n_tchunks = (uint32_t)tchunks.size();
+    fp.n_textures = (uint32_t)td.size();
+    fp.width = tg->width; fp.height = tg->height; fp.samples = tg->samples;
+    fp.color_srgb = format_is_srgb(tg->color_format) ? 1u : 0u;
+    fp.color_bgra = (tg->color_format == RND_FORMAT_B8G8R8A8_SRGB || tg->color_format == RND_FORMAT_B8G8R8A8_UNORM) ? 1u : 0u;
+    fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
+    fp.shard_index = 0; fp.shard_count = 1;
+    fp.area_x0 = cmd->area[0]; fp.area_y0 = cmd->area[1];
+    fp.area_x1 = cmd->area[0] + cmd->area[2] - 1; fp.area_y1 = cmd->area[1] + cmd->area[3] - 1;
+    if (cmd->has_viewport && cmd->has_scissor) {
+        const float* vp = cmd->viewport;
+        fp.half_w = vp[2] * 0.5f; fp.half_h = vp[3] * 0.5f;
+        fp.ox = vp[0] + fp.half_w; fp.oy = vp[1] + fp.half_h;
+        fp.pz = vp[5] - vp[4]; fp.zmin = vp[4];
+        /* fragments land only on pixels whose centre is inside viewport, scissor and render area */
+        int vx0 = (int)ceilf(vp[0] - 0.5f), vy0 = (int)ceilf(vp[1] - 0.5f);
+        int vx1 = (int)ceilf(vp[0] + vp[2] - 0.5f) - 1, vy1 = (int)ceilf(vp[1] + vp[3] - 0.5f) - 1;
+        fp.clamp_x0 = std::max(std::max(vx0, cmd->scissor[0]), std::max(cmd->area[0], 0));
+        fp.clamp_y0 = std::max(std::max(vy0, cmd->scissor[1]), std::max(cmd->area[1], 0));
+        int64_t sx1 = (int64_t)cmd->scissor[0] + cmd->scissor[2] - 1, sy1 = (int64_t)cmd->scissor[1] + cmd->scissor[3] - 1;
+        fp.clamp_x1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vx1, sx1), std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1));
+        fp.clamp_y1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vy1, sy1), std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1));
+    } else {
+        fp.clamp_x0 = 0; fp.clamp_y0 = 0; fp.clamp_x1 = -1; fp.clamp_y1 = -1;
+    }
+    memcpy(fp.clear_color, cmd->clear_color, 16);
+    fp.clear_d24 = host_depth24(cmd->clear_depth);
+    fp.depth_test = (uint32_t)depth_test;
+    fp.depth_write = (uint32_t)depth_test;
+    fp.depth_less = (uint32_t)depth_less;
+    cmd->state = CMD_EXECUTABLE;
+    return RND_SUCCESS;
+}
+
+int rnd_cmd_destroy(rnd_cmd cmd)
+{
+    if (!cmd) return RND_SUCCESS;
+    (void)hipSetDevice(cmd->dev->ordinal);
+    (void)hipStreamSynchronize(cmd->dev->stream);
+    cmd->release_compiled();
+    delete cmd;
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ submit */
+
+int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
+{
+    if (!dev || !cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "submit: bad arguments");
+    if (cmd->dev != dev) return fail(RND_ERROR_INVALID_ARGUMENT, "command buffer belongs to another device");
+    if (cmd->state != CMD_EXECUTABLE) return fail(RND_ERROR_RECORDING, "command buffer is not in the executable state");
+    if (int r = set_device(dev)) return r;
+    FrameParams fp = cmd->fp;
+    fp.shard_index = cmd->shard_index; fp.shard_count = cmd->shard_count;
+    hipStream_t s = dev->stream;
+    const size_t n_tiles = (size_t)fp.tiles_x * fp.tiles_y;
+    const bool prof = dev->profiling;
+    HIP_TRY(hipMemsetAsync(fp.tile_count, 0, n_tiles * 4, s));
+    HIP_TRY(hipMemsetAsync(fp.large_count, 0, 4, s));
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CONSTANTS], s));
+    launch_constants(fp, s);
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_VERTEX], s));
+    launch_vertex(fp, s);
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SETUP], s));
+    launch_setup(fp, s);
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SCAN], s));
+    launch_scan(fp, s);
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_FILL], s));
+    launch_fill(fp, s);
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_TILE], s));
+    launch_tile(fp, s);
+    if (prof) { HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_COUNT], s)); dev->stage_valid = true; }
+    HIP_TRY(hipGetLastError());
+    if (fence) {
+        HIP_TRY(hipEventRecord(fence->ev, s));
+        fence->pending = true;
+    }
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ fences */
+
+int rnd_fence_create(rnd_device dev, rnd_fence* out)
+{
+    if (!dev || !out) return fail(RND_ERROR_INVALID_ARGUMENT, "fence_create: bad arguments");
+    if (int r = set_device(dev)) return r;
+    rnd_fence f = new rnd_fence_t{dev, nullptr, false};
+    hipError_t e = hipEventCreateWithFlags(&f->ev, hipEventDisableTiming);
+    if (e != hipSuccess) { delete f; return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed"); }
+    *out = f;
+    return RND_SUCCESS;
+}
+
+int rnd_fence_wait(rnd_fence fence)
+{
+    if (!fence) return fail(RND_ERROR_INVALID_ARGUMENT, "fence is null");
+    if (!fence->pending) return RND_SUCCESS; /* never submitted: nothing to wait for (the reference only waits on submitted fences, vk_app.cpp:435-444) */
+    if (int r = set_device(fence->dev)) return r;
+    HIP_TRY(hipEventSynchronize(fence->ev));
+    fence->pending = false;
+    return RND_SUCCESS;
+}
+
+int rnd_fence_destroy(rnd_fence fence)
+{
+    if (!fence) return RND_SUCCESS;
+    (void)hipSetDevice(fence->dev->ordinal);
+    (void)hipEventDestroy(fence->ev);
+    delete fence;
+    return RND_SUCCESS;
+}
+
+} // extern "C"

@@ -1,0 +1,133 @@
+/*
+ * rnd_internal.h -- structures shared by the host side of the C ABI and the
+ * gfx950 kernels.  Everything here is plain data laid out for device memory.
+ */
+#ifndef RND_INTERNAL_H
+#define RND_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rnd {
+
+constexpr int TILE_W = 32;           /* pixels per tile side: one workgroup owns a tile's depth/owner words in LDS */
+constexpr int TILE_H = 32;
+constexpr int TILE_SHIFT = 5;
+constexpr int TILE_PIXELS = TILE_W * TILE_H;
+constexpr int TILE_THREADS = 256;
+constexpr int CHUNK = 64;            /* primitives (or vertices) handled by one wave */
+constexpr int MAX_TILES_PER_PRIM = 16; /* primitives touching more tiles go to the pass-wide list */
+constexpr int MAX_TILE_AXIS = 256;   /* tile coordinates are packed in 8 bits */
+constexpr int SUBPIXEL_BITS = 8;
+constexpr float GUARD_BAND = 2.0f;
+
+/* outcode bits kept in the low byte of svtx.xf */
+enum : uint32_t {
+    OC_XNEG = 1, OC_XPOS = 2, OC_YNEG = 4, OC_YPOS = 8, OC_ZNEG = 16, OC_ZPOS = 32,
+    OC_GUARD = 64, OC_INVALID = 128
+};
+
+constexpr uint32_t BBOX_CULLED = 0x000000FFu; /* tx0=255 > tx1=0: nothing to draw */
+
+/* Screen-space vertex written by the vertex kernel: 16 bytes, one dwordx4 per corner in setup */
+struct SVtx {
+    int32_t xf;  /* (x in 24.8) << 8 | outcode */
+    int32_t y;   /* 24.8 */
+    float z;     /* viewport depth */
+    float iw;    /* 1/w */
+};
+
+/* Per-draw record, immutable after recording */
+struct DrawStatic {
+    const uint8_t* vb;   /* vertex 0 of the draw (binding offset and vertex_offset applied) */
+    const uint32_t* ib;  /* index 0 of the draw (binding offset and first_index applied) */
+    const float* ubo;    /* 80 floats: projection, view_projection, view, model, mvp */
+    uint32_t vb_capacity; /* whole vertices readable from vb */
+    uint32_t stride;
+    int32_t off_pos, off_nrm, off_uv;
+    uint32_t tri_count;
+    uint32_t vert_count; /* vertices the vertex kernel transforms: min(max index + 1, vb_capacity) */
+    uint32_t svtx_base;
+    int32_t shader;
+    int32_t texture;
+    uint32_t cull_mode, front_face;
+    uint32_t prim_base;  /* running primitive number of triangle 0 (for diagnostics) */
+    uint32_t pad0;
+    float push[20];      /* vec4 colour, mat4 transform */
+};
+
+/* Per-draw matrices derived from the uniform buffer each time the work executes */
+struct DrawDerived {
+    float clip_m[16];
+    float nrm_m[12];
+};
+
+struct Chunk {
+    uint32_t draw;
+    uint32_t first; /* first vertex / triangle of the chunk inside its draw */
+};
+
+struct TexDesc {
+    const uint8_t* level[16];
+    uint32_t width, height, levels;
+    uint32_t srgb, tiled, filter_linear;
+};
+
+struct IndexRangeJob {
+    const uint32_t* ib;
+    uint32_t count;
+    uint32_t pad;
+};
+
+/* Everything a frame's kernels need; passed by value as the kernel argument */
+struct FrameParams {
+    const DrawStatic* draws;
+    DrawDerived* derived;
+    const Chunk* vchunks;
+    const Chunk* tchunks;
+    const TexDesc* textures;
+    SVtx* svtx;
+    uint32_t* prim_bbox;     /* per primitive slot: packed tile box or BBOX_CULLED */
+    uint32_t* tile_count;    /* per tile */
+    uint32_t* tile_offset;   /* per tile, exclusive scan of tile_count */
+    uint32_t* tile_cursor;   /* per tile */
+    uint32_t* refs;          /* primitive slots grouped by tile */
+    uint32_t* large_list;    /* primitive slots that touch more than MAX_TILES_PER_PRIM tiles */
+    uint32_t* large_count;
+    uint8_t* color;          /* resolved colour, width*height*4 */
+    uint32_t* depth;         /* width*height*samples */
+    const float* srgb_decode; /* 256 floats */
+    const float* srgb_thr;    /* 257 floats */
+    const uint8_t* srgb_lut;  /* SRGB_LUT_SIZE bytes */
+    uint32_t n_draws, n_vchunks, n_tchunks, n_textures;
+    uint32_t width, height, samples;
+    uint32_t color_srgb, color_bgra;
+    uint32_t tiles_x, tiles_y;
+    uint32_t shard_index, shard_count;
+    int32_t clamp_x0, clamp_y0, clamp_x1, clamp_y1; /* inclusive pixel rectangle fragments may land in */
+    int32_t area_x0, area_y0, area_x1, area_y1;     /* inclusive render area (cleared and stored) */
+    float half_w, half_h, ox, oy, pz, zmin;
+    float clear_color[4];
+    uint32_t clear_d24;
+    uint32_t depth_less;     /* 1: LESS, 0: LESS_OR_EQUAL */
+    uint32_t depth_test, depth_write;
+};
+
+/* float bits [2^-13, 1) >> 16: 13 octaves x 128 buckets */
+constexpr uint32_t SRGB_LUT_FIRST = 0x39000000u >> 16; /* 2^-13 */
+constexpr uint32_t SRGB_LUT_LAST = 0x3F800000u >> 16;  /* 1.0 */
+constexpr uint32_t SRGB_LUT_SIZE = SRGB_LUT_LAST - SRGB_LUT_FIRST;
+
+/* launch wrappers (rnd_kernels.hip) */
+void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n_jobs, hipStream_t s);
+void launch_constants(const FrameParams& fp, hipStream_t s);
+void launch_vertex(const FrameParams& fp, hipStream_t s);
+void launch_setup(const FrameParams& fp, hipStream_t s);
+void launch_scan(const FrameParams& fp, hipStream_t s);
+void launch_fill(const FrameParams& fp, hipStream_t s);
+void launch_tile(const FrameParams& fp, hipStream_t s);
+void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
+                const float* srgb_decode, const float* srgb_thr, const uint8_t* srgb_lut, hipStream_t s);
+
+} // namespace rnd
+#endif
