@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the draw path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|0] [--mode views|tiles]
+
+One step = one frame: write the 320-byte uniform block (a new camera, as the reference's
+draw_frame does every frame, base_obj_viewer_app.cpp:90-141) and submit the pre-recorded
+command buffer (vk_app.cpp:463-467).  Vertex, index, texture and instance data are
+resident in HBM before the timed region starts.
+
+N = 1 renders BASELINE.json's configs[1]: 1920x1080, one draw of 1 002 528 triangles.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own
+view of that scene (independent views sharded over GPUs, no collective on the data path,
+weak scaling); --mode tiles instead shards the 32x32 tiles of ONE frame over the ranks
+and gathers the finished colour image with an RCCL all_gather (strong scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from renderer_amd import api, hostmath as hm, scenes  # noqa: E402
+from renderer_amd.runner import SceneRunner  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+
+
+def build_scene(cfg):
+    if cfg == 0:
+        return scenes.config0()
+    if cfg == 1:
+        return scenes.config1()
+    if cfg == 2:
+        return scenes.config2()
+    if cfg == 3:
+        return scenes.config3()
+    raise SystemExit("unknown --config %r" % cfg)
+
+
+def orbit_ubo(scene, step, rank=0):
+    """Per-frame uniform block: the camera swings around the y axis like the sample's
+    mouse orbit (base_obj_viewer_app.cpp:98-125)."""
+    cam = hm.Camera()
+    ang = 0.02 * np.sin(0.37 * step + 0.9 * rank) + 0.05 * rank
+    cam.eye_position = np.array([-2.0 * np.sin(ang), 0.0, -2.0 * np.cos(ang)], dtype=np.float32)
+    model = np.asarray(scene.ubos[0][48:64], dtype=np.float32).reshape(4, 4)
+    return hm.global_ubo(cam, model, scene.width, scene.height)
+
+
+def cpu_baseline(scene, budget_s=12.0):
+    """The CPU oracle on the host cores of this box, same scene, bounded sample."""
+    from oracle import oracle
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)), 64))
+    oracle.render_scene(scene, threads=cores)  # warm-up (page in, build tables)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        oracle.render_scene(scene, threads=cores)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    mpix = scene.width * scene.height * frames / el / 1e6
+    return {"value": round(mpix, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "mtri_per_s": round(scene.triangle_count() * frames / el / 1e6, 3),
+            "sample": "%d frame(s) of %s (%dx%d, %d triangles) in %.2f s" % (
+                frames, scene.name, scene.width, scene.height, scene.triangle_count(), el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=1)
+    ap.add_argument("--mode", choices=["views", "tiles"], default="views")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    scene = build_scene(args.config)
+    run = SceneRunner(scene, ordinal=local_rank)
+    tiles_mode = args.mode == "tiles" and world > 1
+    if tiles_mode:
+        run.cmd.set_tile_shard(rank, world)
+        gather_src = None
+
+    def sync():
+        run.dev.wait_idle()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(i):
+        run.set_ubo(0, orbit_ubo(scene, i, 0 if tiles_mode else rank))
+        run.submit()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    run.dev.wait_idle()
+    if tiles_mode:
+        # gather the finished colour image: every rank contributes its whole (sparse) image,
+        # rank 0 keeps the tiles each rank owns.  One all_gather per frame batch.
+        import ctypes
+        n = scene.width * scene.height * 4
+        mine = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(mine.data_ptr()),
+                                                           ctypes.c_void_p(run.target.color_device_ptr), n, 3)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_total = args.steps * (1 if tiles_mode else world)
+    pixels = scene.width * scene.height
+    mpix = pixels * frames_total / elapsed / 1e6
+    mtri = scene.triangle_count() * frames_total / elapsed / 1e6
+
+    # per-kernel durations, HIP events on the library's own stream
+    roofline = None
+    stages = {}
+    if rank == 0:
+        run.dev.set_profiling(True)
+        acc = {}
+        for i in range(args.profile_steps):
+            step(i)
+            run.dev.wait_idle()
+            for k, v in run.dev.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v
+        run.dev.set_profiling(False)
+        stages = {k: v / max(args.profile_steps, 1) for k, v in acc.items()}
+        dom = max(stages, key=stages.get)
+        bytes_frame = scene.algorithmic_bytes()
+        if tiles_mode:
+            bytes_frame = bytes_frame / world
+        achieved = bytes_frame / (stages[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": bytes_frame,
+                    "kernel_ms": round(stages[dom], 5)}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(scene)
+
+    if rank == 0:
+        out = {
+            "metric": "shaded_mpix_per_s", "value": round(mpix, 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None,
+            "dtype": "f32+i32", "data": "synthetic",
+            "mtri_per_s": round(mtri, 2),
+            "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, 1 sample/pixel" % (
+                scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws)),
+                "sharding": ("tiles of one frame over %d GPUs + RCCL all_gather" % world) if tiles_mode
+                else ("one view per GPU, %d GPUs" % world), "seed": scene.seed},
+            "frame_hbm_frac": round(scene.algorithmic_bytes() * frames_total / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
+            "stage_ms": {k: round(v, 5) for k, v in stages.items()},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    run.destroy()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,14 @@ struct rnd_device_t {
     float* srgb_decode = nullptr;
     float* srgb_thr = nullptr;
     uint8_t* srgb_lut = nullptr;
+    /* pinned ring for small host->device writes (the per-frame uniform block): the copy is
+     * queued on the stream and the call returns without waiting for the device */
+    static constexpr int STAGE_SLOTS = 64;
+    static constexpr size_t STAGE_SLOT_BYTES = 4096;
+    uint8_t* stage_host = nullptr;
+    hipEvent_t stage_ev[STAGE_SLOTS] = {};
+    bool stage_used[STAGE_SLOTS] = {};
+    int stage_next = 0;
     bool profiling = false;
     hipEvent_t ev[RND_STAGE_COUNT + 1] = {};
     float stage_ms[RND_STAGE_COUNT] = {};
@@ -289,6 +297,8 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
     HIP_TRY(hipMemcpy(dev->srgb_thr, thr.data(), 257 * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dev->srgb_lut, lut.data(), SRGB_LUT_SIZE, hipMemcpyHostToDevice));
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) HIP_TRY(hipEventCreate(&dev->ev[i]));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->stage_host), rnd_device_t::STAGE_SLOTS * rnd_device_t::STAGE_SLOT_BYTES, hipHostMallocDefault));
+    for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&dev->stage_ev[i], hipEventDisableTiming));
     *out = dev;
     return RND_SUCCESS;
 }
@@ -302,6 +312,8 @@ int rnd_device_destroy(rnd_device dev)
     if (dev->srgb_thr) (void)hipFree(dev->srgb_thr);
     if (dev->srgb_lut) (void)hipFree(dev->srgb_lut);
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) if (dev->ev[i]) (void)hipEventDestroy(dev->ev[i]);
+    for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) if (dev->stage_ev[i]) (void)hipEventDestroy(dev->stage_ev[i]);
+    if (dev->stage_host) (void)hipHostFree(dev->stage_host);
     if (dev->own_stream && dev->stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return RND_SUCCESS;
@@ -357,9 +369,21 @@ int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t 
     if (!buf || !src) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write: bad arguments");
     if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write: range outside the buffer");
     if (int r = set_device(buf->dev)) return r;
-    /* stream-ordered after earlier submits; the host memory is consumed before return (pageable copy) */
-    HIP_TRY(hipMemcpyAsync(buf->ptr + offset, src, (size_t)bytes, hipMemcpyHostToDevice, buf->dev->stream));
-    HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+    rnd_device dev = buf->dev;
+    if (bytes <= rnd_device_t::STAGE_SLOT_BYTES) {
+        /* stream-ordered after earlier submits: a frame already queued still sees the old bytes */
+        int slot = dev->stage_next;
+        dev->stage_next = (slot + 1) % rnd_device_t::STAGE_SLOTS;
+        if (dev->stage_used[slot]) HIP_TRY(hipEventSynchronize(dev->stage_ev[slot]));
+        uint8_t* staging = dev->stage_host + (size_t)slot * rnd_device_t::STAGE_SLOT_BYTES;
+        memcpy(staging, src, (size_t)bytes);
+        HIP_TRY(hipMemcpyAsync(buf->ptr + offset, staging, (size_t)bytes, hipMemcpyHostToDevice, dev->stream));
+        HIP_TRY(hipEventRecord(dev->stage_ev[slot], dev->stream));
+        dev->stage_used[slot] = true;
+        return RND_SUCCESS;
+    }
+    HIP_TRY(hipMemcpyAsync(buf->ptr + offset, src, (size_t)bytes, hipMemcpyHostToDevice, dev->stream));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
     return RND_SUCCESS;
 }
 

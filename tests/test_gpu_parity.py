@@ -46,3 +46,9 @@ def test_instances_small(device, oracle):
     for b2f in (True, False):
         mism = compare(scenes.instanced_spheres(512, 288, 12, 8, 4, 2, back_to_front=b2f, tex_size=128), device, oracle)
         assert mism == 0
+
+
+def test_config1_full(device, oracle):
+    """BASELINE configs[1] at full size: 1920x1080, 1 002 528 triangles."""
+    mism = compare(scenes.config1(), device, oracle, threads=16)
+    assert mism == 0
