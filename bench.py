@@ -107,7 +107,6 @@ def main():
     tiles_mode = args.mode == "tiles" and world > 1
     if tiles_mode:
         run.cmd.set_tile_shard(rank, world)
-        gather_src = None
 
     def sync():
         run.dev.wait_idle()
@@ -119,6 +118,18 @@ def main():
         run.set_ubo(0, orbit_ubo(scene, i, 0 if tiles_mode else rank))
         run.submit()
 
+    gather_ms = None
+    if tiles_mode:
+        from renderer_amd import sharding
+        mine = torch.empty((scene.height, scene.width, 4), dtype=torch.uint8, device="cuda")
+
+        def step(i):  # noqa: F811 - one frame = render own tiles, then gather the colour image
+            run.set_ubo(0, orbit_ubo(scene, i, 0))
+            run.submit()
+            run.target.copy_color(mine.data_ptr())
+            run.dev.wait_idle()
+            return sharding.gather_frame(mine, dist, world)
+
     for i in range(args.warmup):
         step(i)
     sync()
@@ -126,18 +137,8 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     run.dev.wait_idle()
-    if tiles_mode:
-        # gather the finished colour image: every rank contributes its whole (sparse) image,
-        # rank 0 keeps the tiles each rank owns.  One all_gather per frame batch.
-        import ctypes
-        n = scene.width * scene.height * 4
-        mine = torch.empty(n, dtype=torch.uint8, device="cuda")
-        ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(mine.data_ptr()),
-                                                           ctypes.c_void_p(run.target.color_device_ptr), n, 3)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        torch.cuda.synchronize()
     if dist is not None:
+        torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

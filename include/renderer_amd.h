@@ -148,6 +148,10 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
  * Either pointer may be NULL.  Waits for the device. */
 int rnd_target_read(rnd_target target, void* color_out, uint32_t* depth_out);
 void* rnd_target_color_device_ptr(rnd_target target); /* resolved colour image in device memory, row-major */
+/* no reference analogue: queue a device-to-device copy of the resolved colour image
+ * (width*height*4 bytes) on the device's stream, e.g. into the send buffer of the
+ * multi-GPU frame gather.  Does not wait. */
+int rnd_target_copy_color(rnd_target target, void* device_dst);
 int rnd_target_destroy(rnd_target target);
 
 /* vkCreateGraphicsPipelines (test_ktx_app.cpp:607-620) */

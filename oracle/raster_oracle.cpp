@@ -744,7 +744,10 @@ void render_band(const band_job* job)
             for (int s = 0; s < S; ++s) {
                 size_t gi = ((size_t)y * W + x) * S + s;
                 size_t li = ((size_t)(y - job->y0) * W + x) * S + s;
-                job->out_depth[gi] = dclear;
+                /* loadOp CLEAR applies to the render area; pixels outside it are not touched
+                 * (they read back as the zeros a fresh target holds) */
+                const bool in_area = x >= p->area[0] && x < p->area[0] + p->area[2] && y >= p->area[1] && y < p->area[1] + p->area[3];
+                job->out_depth[gi] = in_area ? dclear : 0u;
                 if (job->out_prim) job->out_prim[gi] = 0xFFFFFFFFu;
                 if (job->literal) memcpy(&sample_rgba[li * 4], p->clear_color, 16);
                 else win[li].valid = 0;
@@ -819,6 +822,10 @@ void render_band(const band_job* job)
     /* resolve + store */
     for (int y = job->y0; y <= job->y1; ++y) {
         for (int x = 0; x < W; ++x) {
+            if (!(x >= p->area[0] && x < p->area[0] + p->area[2] && y >= p->area[1] && y < p->area[1] + p->area[3])) {
+                memset(job->out_color + ((size_t)y * W + x) * 4, 0, 4);
+                continue;
+            }
             float acc[4];
             float smp[4][4];
             for (int s = 0; s < S; ++s) {

@@ -17,7 +17,7 @@ SYMBOLS = [
     "rnd_buffer_create", "rnd_buffer_write", "rnd_buffer_write_device", "rnd_buffer_read", "rnd_buffer_destroy",
     "rnd_texture_create_2d", "rnd_texture_create_levels", "rnd_texture_level_count", "rnd_texture_read_level",
     "rnd_texture_destroy",
-    "rnd_target_create", "rnd_target_read", "rnd_target_color_device_ptr", "rnd_target_destroy",
+    "rnd_target_create", "rnd_target_read", "rnd_target_color_device_ptr", "rnd_target_copy_color", "rnd_target_destroy",
     "rnd_pipeline_create", "rnd_pipeline_destroy",
     "rnd_cmd_create", "rnd_cmd_begin", "rnd_cmd_begin_pass", "rnd_cmd_set_viewport", "rnd_cmd_set_scissor",
     "rnd_cmd_bind_pipeline", "rnd_cmd_bind_vertex_buffer", "rnd_cmd_bind_index_buffer", "rnd_cmd_bind_uniform",
@@ -82,6 +82,7 @@ def load():
         "rnd_target_create": (C.c_int, [vp, u32, u32, i32, i32, u32, C.POINTER(vp)]),
         "rnd_target_read": (C.c_int, [vp, vp, vp]),
         "rnd_target_color_device_ptr": (vp, [vp]),
+        "rnd_target_copy_color": (C.c_int, [vp, vp]),
         "rnd_target_destroy": (C.c_int, [vp]),
         "rnd_pipeline_create": (C.c_int, [vp, C.POINTER(PipelineInfo), C.POINTER(vp)]),
         "rnd_pipeline_destroy": (C.c_int, [vp]),

@@ -177,6 +177,10 @@ class Target(_Handle):
     def color_device_ptr(self):
         return _lib.load().rnd_target_color_device_ptr(self.h)
 
+    def copy_color(self, device_ptr):
+        """Queue a device-to-device copy of the colour image; does not wait."""
+        _check(_lib.load().rnd_target_copy_color(self.h, C.c_void_p(device_ptr)))
+
 
 class Pipeline(_Handle):
     _destroy_name = "rnd_pipeline_destroy"

@@ -535,6 +535,14 @@ int rnd_target_read(rnd_target target, void* color_out, uint32_t* depth_out)
 
 void* rnd_target_color_device_ptr(rnd_target target) { return target ? target->color : nullptr; }
 
+int rnd_target_copy_color(rnd_target target, void* device_dst)
+{
+    if (!target || !device_dst) return fail(RND_ERROR_INVALID_ARGUMENT, "target_copy_color: bad arguments");
+    if (int r = set_device(target->dev)) return r;
+    HIP_TRY(hipMemcpyAsync(device_dst, target->color, (size_t)target->width * target->height * 4, hipMemcpyDeviceToDevice, target->dev->stream));
+    return RND_SUCCESS;
+}
+
 int rnd_target_destroy(rnd_target target)
 {
     if (!target) return RND_SUCCESS;

@@ -1,0 +1,291 @@
+"""GPU parity on directed and randomised edge cases: clipping, guard band, large primitives,
+ties in depth, cull state, viewport/scissor/area rectangles, odd target sizes, 4x
+multisampling, sampler modes, target formats, uniform re-read, tile sharding."""
+import numpy as np
+import pytest
+
+import helpers
+from renderer_amd import api, hostmath as hm, scenes
+from renderer_amd.runner import SceneRunner
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_render(scene, device):
+    r = SceneRunner(scene, device)
+    try:
+        return r.render()
+    finally:
+        r.destroy()
+
+
+def check(scene, device, oracle, exact_color=True, threads=8):
+    color, depth = gpu_render(scene, device)
+    ocolor, odepth, _ = oracle.render_scene(scene, threads=threads)
+    assert np.array_equal(depth, odepth), "depth words differ at %d samples" % int((depth != odepth).sum())
+    diff = np.abs(color.astype(np.int32) - ocolor.astype(np.int32))
+    assert diff.max() <= 1, "colour differs by %d at %d channels" % (int(diff.max()), int((diff > 1).sum()))
+    if exact_color:
+        assert diff.max() == 0, "%d channels off by one" % int((diff != 0).sum())
+    return color, depth
+
+
+def tex(size=64, seed=1, **kw):
+    d = dict(texels=scenes.checker_texture(size, seed), gen_mips=True, filtering=1, tiled=False, fmt=43)
+    d.update(kw)
+    return d
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_soup_random_depth(device, oracle, seed):
+    check(helpers.soup_scene(257, 131, 1500, seed, n_draws=4), device, oracle)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_soup_depth_ties(device, oracle, seed):
+    """Flat triangles on a few depth levels: equal-depth fragments decide by submission order."""
+    check(helpers.soup_scene(200, 120, 1200, 100 + seed, depth_levels=3, n_draws=5), device, oracle)
+
+
+def test_soup_depth_ties_less(device, oracle):
+    check(helpers.soup_scene(200, 120, 1200, 7, depth_levels=3, n_draws=5, pipeline_kw=dict(depth_compare=1)), device, oracle)
+
+
+def test_soup_near_far_planes(device, oracle):
+    """z from -0.4 to 1.4: primitives cross z=0 and z=w and are clipped."""
+    check(helpers.soup_scene(192, 128, 800, 21, z_range=(-0.4, 1.4), max_extent=1.0), device, oracle)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_perspective_soup_clipping(device, oracle, seed):
+    """Triangles all around the eye: near plane, far plane, w <= 0 and the guard band."""
+    sc = helpers.perspective_soup(320, 200, 600, 40 + seed, near_cross=True, shader=scenes.SHADER_TEST_KTX, texture=tex(),
+                                  pipeline_kw=dict(cull_mode=0))
+    check(sc, device, oracle)
+
+
+def test_perspective_soup_textured_lod(device, oracle):
+    sc = helpers.perspective_soup(400, 300, 500, 50, near_cross=False, shader=scenes.SHADER_TEST_KTX, texture=tex(256),
+                                  pipeline_kw=dict(cull_mode=0))
+    check(sc, device, oracle)
+
+
+def test_huge_triangles(device, oracle):
+    """Primitives far larger than the screen (through the guard band) and exactly screen sized."""
+    W, H = 300, 170
+    tris = [[(-4000.0, -3000.0, 0.9), (-4000.0, 5000.0, 0.9), (6000.0, 100.0, 0.8)],
+            [(0.0, 0.0, 0.5), (0.0, float(H), 0.5), (float(W), 0.0, 0.5)],
+            [(float(W), float(H), 0.4), (float(W), 0.0, 0.4), (0.0, float(H), 0.4)],
+            [(10.0, 10.0, 0.3), (10.0, 150.0, 0.2), (250.0, 80.0, 0.1)]]
+    check(helpers.window_triangles(W, H, tris, pipeline_kw=dict(cull_mode=0)), device, oracle)
+
+
+def test_fill_rule_ties_on_gpu(device, oracle):
+    """Quarter-pixel corners put many samples exactly on edges."""
+    rng = np.random.RandomState(3)
+    W = H = 48
+    tris = []
+    for _ in range(150):
+        pts = rng.randint(0, 4 * W + 1, size=(3, 2)) / 4.0
+        z = rng.randint(1, 8) / 8.0
+        tris.append([(float(x), float(y), z) for x, y in pts])
+    check(helpers.window_triangles(W, H, tris, pipeline_kw=dict(cull_mode=0)), device, oracle)
+
+
+@pytest.mark.parametrize("cull,ff", [(0, 0), (1, 0), (2, 0), (2, 1), (3, 0)])
+def test_cull_state(device, oracle, cull, ff):
+    check(helpers.soup_scene(128, 96, 400, 5, pipeline_kw=dict(cull_mode=cull, front_face=ff)), device, oracle)
+
+
+def test_viewport_scissor_area(device, oracle):
+    sc = helpers.soup_scene(160, 120, 600, 9)
+    sc.viewport = (20.0, 10.0, 100.0, 90.0, 0.1, 0.9)
+    sc.scissor = (30, 5, 80, 70)
+    sc.area = (8, 8, 140, 100)
+    color, depth = check(sc, device, oracle)
+    assert (depth[0:8] == 0).all() and (color[0:8] == 0).all()  # outside the render area nothing is stored
+    assert (depth[8, 8:148, 0] == oracle.load().orc_depth24(1.0)).all()
+
+
+@pytest.mark.parametrize("wh", [(1, 1), (33, 31), (101, 67), (640, 3)])
+def test_odd_target_sizes(device, oracle, wh):
+    check(helpers.soup_scene(wh[0], wh[1], 300, 13), device, oracle)
+
+
+def test_empty_pass_and_empty_draw(device, oracle):
+    sc = scenes.Scene(70, 40)
+    sc.clear_color = (0.25, 0.5, 0.75, 1.0)
+    color, depth = check(sc, device, oracle)
+    assert (depth == 0xFFFFFF).all()
+    sc = helpers.soup_scene(70, 40, 10, 1)
+    sc.draws[0]["index_count"] = 2  # fewer than one triangle
+    check(sc, device, oracle)
+
+
+def test_index_out_of_range_drops_primitive(device, oracle):
+    sc = helpers.soup_scene(64, 64, 40, 2)
+    ib = sc.ibs[0].copy()
+    ib[4] = 10 ** 6
+    ib[30] = 0xFFFFFFFF
+    sc.ibs[0] = ib
+    check(sc, device, oracle)
+
+
+def test_sub_geometries_share_buffers(device, oracle):
+    """The reference's layout: one vertex buffer bound at a byte offset per sub-geometry,
+    indices local to it, index buffer bound at indices_offset*4 (test_ktx_app.cpp:728-732)."""
+    a = helpers.soup_scene(128, 96, 100, 31)
+    b = helpers.soup_scene(128, 96, 150, 32)
+    sc = scenes.Scene(128, 96)
+    sc.vbs.append(np.concatenate([a.vbs[0], b.vbs[0]]))
+    sc.ibs.append(np.concatenate([a.ibs[0], b.ibs[0]]))
+    sc.ubos.append(a.ubos[0])
+    sc.pipelines.append(scenes.default_pipeline(scenes.SHADER_PUSH_CONSTANTS))
+    sc.draws.append(dict(pipeline=0, vb=0, vb_offset=0, ib=0, ib_offset=0, ubo=0, texture=-1,
+                         push=a.draws[0]["push"], index_count=300, first_index=0, vertex_offset=0))
+    sc.draws.append(dict(pipeline=0, vb=0, vb_offset=int(a.vbs[0].nbytes), ib=0, ib_offset=300 * 4, ubo=0, texture=-1,
+                         push=b.draws[0]["push"], index_count=450, first_index=0, vertex_offset=0))
+    sc.draws.append(dict(pipeline=0, vb=0, vb_offset=0, ib=0, ib_offset=0, ubo=0, texture=-1,
+                         push=b.draws[0]["push"], index_count=150, first_index=300, vertex_offset=300))
+    check(sc, device, oracle)
+
+
+def test_vertex_formats(device, oracle):
+    """Position-only (stride 12) and position+uv (stride 20) layouts (obj_loader.cpp:98-109)."""
+    base = helpers.soup_scene(96, 64, 200, 17, shader=scenes.SHADER_DUMMY, texture=tex())
+    v = base.vbs[0]
+    for cols, stride, on, ou in (([0, 1, 2], 12, None, None), ([0, 1, 2, 6, 7], 20, None, 12)):
+        sc = helpers.soup_scene(96, 64, 200, 17, shader=scenes.SHADER_DUMMY, texture=tex())
+        sc.vbs[0] = np.ascontiguousarray(v[:, cols])
+        sc.pipelines[0].update(stride=stride, off_nrm=on, off_uv=ou)
+        check(sc, device, oracle)
+
+
+@pytest.mark.parametrize("shader", [scenes.SHADER_DUMMY, scenes.SHADER_TEST_KTX, scenes.SHADER_PUSH_CONSTANTS])
+def test_msaa4(device, oracle, shader):
+    """4x multisampling + resolve, the state of the third sample (dummy_obj_viewer_app.cpp:314-323, 468-520)."""
+    sc = scenes.config0(200, 120, shader=shader, samples=4, tex_size=64, segments=24, rings=12)
+    check(sc, device, oracle)
+
+
+def test_msaa4_soup_with_clipping(device, oracle):
+    sc = helpers.perspective_soup(160, 100, 300, 61, near_cross=True, samples=4, pipeline_kw=dict(cull_mode=0))
+    check(sc, device, oracle)
+    check(helpers.soup_scene(120, 80, 500, 62, depth_levels=3, samples=4, n_draws=3), device, oracle)
+
+
+@pytest.mark.parametrize("kw", [dict(filtering=0), dict(tiled=True), dict(gen_mips=False), dict(fmt=37),
+                                dict(filtering=0, tiled=True, gen_mips=True)])
+def test_sampler_modes(device, oracle, kw):
+    sc = helpers.perspective_soup(200, 150, 200, 70, near_cross=False, shader=scenes.SHADER_DUMMY, texture=tex(128, 2, **kw),
+                                  pipeline_kw=dict(cull_mode=0))
+    sc.vbs[0][:, 6:8] = sc.vbs[0][:, 6:8] * 3.0 - 1.0  # uv outside [0,1]: clamp vs repeat
+    check(sc, device, oracle)
+
+
+def test_npot_texture_and_mip_chain(device, oracle):
+    for shape in [(100, 60), (64, 64), (1, 37), (130, 130)]:
+        t = scenes.checker_texture(max(shape), 4)[:shape[1], :shape[0]].copy()
+        for fmt in (43, 37):
+            gtex = api.Texture(device, t, fmt=fmt, gen_mips=True)
+            levels = oracle.mip_chain(t, True, srgb=(fmt == 43))
+            assert gtex.level_count == len(levels)
+            for l, ref in enumerate(levels):
+                assert np.array_equal(gtex.read_level(l), ref), "level %d of %s fmt %d" % (l, shape, fmt)
+            gtex.destroy()
+
+
+def test_texture_channel_expansion(device, oracle):
+    """1-, 2- and 3-channel uploads take the reference's view swizzles (tools.cpp:474-509)."""
+    rgb = scenes.checker_texture(32, 5)[..., :3].copy()
+    g = api.Texture(device, rgb, fmt=api.FORMAT_R8G8B8_SRGB, gen_mips=False)
+    out = g.read_level(0)
+    assert np.array_equal(out[..., :3], rgb) and (out[..., 3] == 255).all()
+    g.destroy()
+    r = rgb[..., 0].copy()
+    g = api.Texture(device, r, fmt=api.FORMAT_R8_SRGB, gen_mips=False)
+    out = g.read_level(0)
+    assert np.array_equal(out[..., 0], r) and np.array_equal(out[..., 1], r) and np.array_equal(out[..., 2], r)
+    g.destroy()
+
+
+@pytest.mark.parametrize("fmt", [37, 43, 44, 50])
+def test_target_formats(device, oracle, fmt):
+    sc = scenes.config0(160, 90, shader=scenes.SHADER_PUSH_CONSTANTS, tex_size=32, segments=16, rings=8)
+    sc.color_format = fmt
+    check(sc, device, oracle)
+
+
+def test_uniforms_are_read_at_execution(device, oracle):
+    """The command buffer is recorded once; writing the uniform buffer between two submits
+    changes the second frame (base_obj_viewer_app.cpp:134-138, vk_app.cpp:463-467)."""
+    sc = scenes.config0(256, 144, tex_size=64, segments=24, rings=12)
+    r = SceneRunner(sc, device)
+    try:
+        c1, d1 = r.render()
+        cam = hm.Camera()
+        cam.eye_position = np.array([0.4, 0.3, -2.2], dtype=np.float32)
+        ubo2 = hm.global_ubo(cam, sc.ubos[0][48:64].reshape(4, 4), sc.width, sc.height)
+        r.set_ubo(0, ubo2)
+        c2, d2 = r.render()
+    finally:
+        r.destroy()
+    assert not np.array_equal(d1, d2)
+    sc.ubos[0] = ubo2
+    oc, od, _ = oracle.render_scene(sc, threads=4)
+    assert np.array_equal(d2, od) and np.array_equal(c2, oc)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_tile_shards_compose_the_frame(device, oracle, shards):
+    """Sort-first sharding: shard k draws only tiles t with t % n == k; together they are the frame."""
+    sc = scenes.instanced_spheres(300, 200, 6, 4, 3, 5, tex_size=64)
+    full_c, full_d = gpu_render(sc, device)
+    acc_c, acc_d = np.zeros_like(full_c), np.zeros_like(full_d)
+    tiles_x = (sc.width + 31) // 32
+    for k in range(shards):
+        r = SceneRunner(sc, device)
+        try:
+            r.cmd.set_tile_shard(k, shards)
+            c, d = r.render()
+        finally:
+            r.destroy()
+        for ty in range((sc.height + 31) // 32):
+            for tx in range(tiles_x):
+                sl = (slice(ty * 32, ty * 32 + 32), slice(tx * 32, tx * 32 + 32))
+                if (ty * tiles_x + tx) % shards == k:
+                    acc_c[sl], acc_d[sl] = c[sl], d[sl]
+                else:
+                    assert (c[sl] == 0).all()  # a shard leaves other shards' tiles untouched
+    assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
+
+
+def test_resubmission_is_idempotent(device):
+    sc = helpers.soup_scene(200, 150, 2000, 77, depth_levels=2, n_draws=7)
+    r = SceneRunner(sc, device)
+    try:
+        c1, d1 = r.render()
+        for _ in range(5):
+            r.submit()
+        c2, d2 = r.render()
+    finally:
+        r.destroy()
+    assert np.array_equal(c1, c2) and np.array_equal(d1, d2)
+
+
+def test_error_codes(device):
+    with pytest.raises(api.RendererError) as e:
+        api.Target(device, 0, 10)
+    assert e.value.code == -1
+    with pytest.raises(api.RendererError) as e:
+        api.Pipeline(device, api.SHADER_TEST_KTX, depth_compare=7)
+    assert e.value.code == -8 and "LESS" in e.value.msg
+    with pytest.raises(api.RendererError) as e:
+        api.Texture(device, np.zeros((4, 4, 4), np.uint8), fmt=129)
+    assert e.value.code == -11 and "unsupported pixels format" in e.value.msg
+    cmd = api.CommandBuffer(device)
+    with pytest.raises(api.RendererError) as e:
+        cmd.draw_indexed(3)
+    assert e.value.code == -12
+    cmd.destroy()
+    cmd.destroy()  # destroy is idempotent (handlers.hpp:108-113)
