@@ -76,6 +76,7 @@ struct rnd_device_t {
     hipEvent_t stage_ev[STAGE_SLOTS] = {};
     bool stage_used[STAGE_SLOTS] = {};
     int stage_next = 0;
+    uint32_t* status_host = nullptr; /* pinned word the tile kernel writes when a work list overflowed */
     bool profiling = false;
     hipEvent_t ev[RND_STAGE_COUNT + 1] = {};
     float stage_ms[RND_STAGE_COUNT] = {};
@@ -159,15 +160,19 @@ struct rnd_cmd_t {
     DeviceArray<Chunk> d_vchunks, d_tchunks;
     DeviceArray<TexDesc> d_textures;
     DeviceArray<SVtx> d_svtx;
-    DeviceArray<uint32_t> d_prim_bbox, d_tile_count, d_tile_offset, d_tile_cursor, d_refs, d_large_list, d_large_count;
+    DeviceArray<PrimRec> d_prim_rec;
+    DeviceArray<TileEntry> d_tile_lists;
+    DeviceArray<LargeEntry> d_large_list;
+    DeviceArray<ClipTri> d_clip_tris;
+    DeviceArray<uint32_t> d_tile_count, d_clip_list, d_counters;
     FrameParams fp = {};
     uint32_t shard_index = 0, shard_count = 1;
 
     void release_compiled()
     {
         d_draws.release(); d_derived.release(); d_vchunks.release(); d_tchunks.release(); d_textures.release();
-        d_svtx.release(); d_prim_bbox.release(); d_tile_count.release(); d_tile_offset.release(); d_tile_cursor.release();
-        d_refs.release(); d_large_list.release(); d_large_count.release();
+        d_svtx.release(); d_prim_rec.release(); d_tile_lists.release(); d_large_list.release(); d_clip_tris.release();
+        d_tile_count.release(); d_clip_list.release(); d_counters.release();
     }
 };
 
@@ -177,6 +182,16 @@ int set_device(rnd_device dev)
 {
     HIP_TRY(hipSetDevice(dev->ordinal));
     return RND_SUCCESS;
+}
+
+/* after the stream has been waited for: did a frame overflow one of its work lists? */
+int report_overflow(rnd_device dev)
+{
+    if (!dev->status_host || !*dev->status_host) return RND_SUCCESS;
+    const uint32_t ovf = *dev->status_host;
+    *dev->status_host = 0;
+    return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, std::string("a work list overflowed while rendering (flags ") + std::to_string(ovf) +
+                "; pass-wide list=1, clip list=2, clipped triangles=4): the frame is incomplete");
 }
 
 bool format_is_srgb(int32_t f)
@@ -299,6 +314,8 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) HIP_TRY(hipEventCreate(&dev->ev[i]));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->stage_host), rnd_device_t::STAGE_SLOTS * rnd_device_t::STAGE_SLOT_BYTES, hipHostMallocDefault));
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&dev->stage_ev[i], hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->status_host), 64, hipHostMallocDefault));
+    *dev->status_host = 0;
     *out = dev;
     return RND_SUCCESS;
 }
@@ -314,6 +331,7 @@ int rnd_device_destroy(rnd_device dev)
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) if (dev->ev[i]) (void)hipEventDestroy(dev->ev[i]);
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) if (dev->stage_ev[i]) (void)hipEventDestroy(dev->stage_ev[i]);
     if (dev->stage_host) (void)hipHostFree(dev->stage_host);
+    if (dev->status_host) (void)hipHostFree(dev->status_host);
     if (dev->own_stream && dev->stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return RND_SUCCESS;
@@ -324,7 +342,7 @@ int rnd_device_wait_idle(rnd_device dev)
     if (!dev) return fail(RND_ERROR_INVALID_ARGUMENT, "device is null");
     if (int r = set_device(dev)) return r;
     HIP_TRY(hipStreamSynchronize(dev->stream));
-    return RND_SUCCESS;
+    return report_overflow(dev);
 }
 
 void* rnd_device_stream(rnd_device dev) { return dev ? static_cast<void*>(dev->stream) : nullptr; }
@@ -530,7 +548,7 @@ int rnd_target_read(rnd_target target, void* color_out, uint32_t* depth_out)
     size_t px = (size_t)target->width * target->height;
     if (color_out) HIP_TRY(hipMemcpy(color_out, target->color, px * 4, hipMemcpyDeviceToHost));
     if (depth_out) HIP_TRY(hipMemcpy(depth_out, target->depth, px * target->samples * 4, hipMemcpyDeviceToHost));
-    return RND_SUCCESS;
+    return report_overflow(target->dev);
 }
 
 void* rnd_target_color_device_ptr(rnd_target target) { return target ? target->color : nullptr; }
@@ -866,7 +884,16 @@ int rnd_cmd_end(rnd_cmd cmd)
     const uint32_t tiles_x = (tg->width + TILE_W - 1) / TILE_W, tiles_y = (tg->height + TILE_H - 1) / TILE_H;
     const size_t n_tiles = (size_t)tiles_x * tiles_y;
     const size_t slots = tchunks.size() * CHUNK;
-    const size_t per_prim = std::min<size_t>(MAX_TILES_PER_PRIM, n_tiles);
+    if (slots > SLOT_MASK) return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "pass holds more than 2^28 primitive slots");
+    if (n > SLOT_MASK) return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "pass holds more than 2^28 draws");
+    /* Fixed-capacity tile lists: the largest power of two that keeps all lists within 2 GiB
+     * (HBM is 288 GB; only the entries written are ever touched).  Spill goes to the pass-wide list. */
+    size_t tile_cap = 16384;
+    while (tile_cap > 256 && tile_cap * n_tiles * sizeof(TileEntry) > (size_t(2) << 30)) tile_cap >>= 1;
+    while (tile_cap > 256 && tile_cap / 2 >= slots) tile_cap >>= 1;
+    const size_t large_cap = 2 * slots + 65536;
+    const size_t clip_cap = slots ? slots : 1;
+    const size_t clip_tri_cap = std::min<size_t>(MAX_FAN * slots, 2 * slots + 65536) + 1;
 
     cmd->release_compiled();
     HIP_TRY(cmd->d_draws.upload(ds));
@@ -875,21 +902,29 @@ int rnd_cmd_end(rnd_cmd cmd)
     HIP_TRY(cmd->d_tchunks.upload(tchunks));
     HIP_TRY(cmd->d_textures.upload(td));
     HIP_TRY(cmd->d_svtx.resize((size_t)svtx_total));
-    HIP_TRY(cmd->d_prim_bbox.resize(slots));
+    HIP_TRY(cmd->d_prim_rec.resize(slots));
     HIP_TRY(cmd->d_tile_count.resize(n_tiles));
-    HIP_TRY(cmd->d_tile_offset.resize(n_tiles));
-    HIP_TRY(cmd->d_tile_cursor.resize(n_tiles));
-    HIP_TRY(cmd->d_refs.resize(slots * per_prim));
-    HIP_TRY(cmd->d_large_list.resize(slots));
-    HIP_TRY(cmd->d_large_count.resize(1));
+    HIP_TRY(cmd->d_tile_lists.resize(n_tiles * tile_cap));
+    HIP_TRY(cmd->d_large_list.resize(large_cap));
+    HIP_TRY(cmd->d_clip_list.resize(clip_cap));
+    HIP_TRY(cmd->d_clip_tris.resize(clip_tri_cap));
+    HIP_TRY(cmd->d_counters.resize(CTR_COUNT));
 
     FrameParams& fp = cmd->fp;
     memset(&fp, 0, sizeof(fp));
     fp.draws = cmd->d_draws.ptr; fp.derived = cmd->d_derived.ptr;
     fp.vchunks = cmd->d_vchunks.ptr; fp.tchunks = cmd->d_tchunks.ptr; fp.textures = cmd->d_textures.ptr;
-    fp.svtx = cmd->d_svtx.ptr; fp.prim_bbox = cmd->d_prim_bbox.ptr;
-    fp.tile_count = cmd->d_tile_count.ptr; fp.tile_offset = cmd->d_tile_offset.ptr; fp.tile_cursor = cmd->d_tile_cursor.ptr;
-    fp.refs = cmd->d_refs.ptr; fp.large_list = cmd->d_large_list.ptr; fp.large_count = cmd->d_large_count.ptr;
+    fp.svtx = cmd->d_svtx.ptr; fp.prim_rec = cmd->d_prim_rec.ptr;
+    fp.tile_count = cmd->d_tile_count.ptr; fp.tile_lists = cmd->d_tile_lists.ptr;
+    fp.large_list = cmd->d_large_list.ptr; fp.clip_list = cmd->d_clip_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
+    fp.counters = cmd->d_counters.ptr;
+    fp.tile_capacity = (uint32_t)tile_cap; fp.large_capacity = (uint32_t)large_cap;
+    fp.clip_capacity = (uint32_t)clip_cap; fp.clip_tri_capacity = (uint32_t)clip_tri_cap;
+    {
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, dev->status_host, 0));
+        fp.status_host = static_cast<uint32_t*>(dp);
+    }
     fp.color = tg->color; fp.depth = tg->depth;
     fp.srgb_decode = dev->srgb_decode; fp.srgb_thr = dev->srgb_thr; fp.srgb_lut = dev->srgb_lut;
     fp.n_draws = (uint32_t)n; fp.n_vchunks = (uint32_t)vchunks.size(); fp.n_tchunks = (uint32_t)tchunks.size();
@@ -950,17 +985,15 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     const size_t n_tiles = (size_t)fp.tiles_x * fp.tiles_y;
     const bool prof = dev->profiling;
     HIP_TRY(hipMemsetAsync(fp.tile_count, 0, n_tiles * 4, s));
-    HIP_TRY(hipMemsetAsync(fp.large_count, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(fp.counters, 0, CTR_COUNT * 4, s));
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CONSTANTS], s));
     launch_constants(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_VERTEX], s));
     launch_vertex(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SETUP], s));
     launch_setup(fp, s);
-    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SCAN], s));
-    launch_scan(fp, s);
-    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_FILL], s));
-    launch_fill(fp, s);
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CLIP], s));
+    launch_clip(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_TILE], s));
     launch_tile(fp, s);
     if (prof) { HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_COUNT], s)); dev->stage_valid = true; }
@@ -992,7 +1025,7 @@ int rnd_fence_wait(rnd_fence fence)
     if (int r = set_device(fence->dev)) return r;
     HIP_TRY(hipEventSynchronize(fence->ev));
     fence->pending = false;
-    return RND_SUCCESS;
+    return report_overflow(fence->dev);
 }
 
 int rnd_fence_destroy(rnd_fence fence)

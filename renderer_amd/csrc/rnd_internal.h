@@ -17,6 +17,8 @@ constexpr int TILE_PIXELS = TILE_W * TILE_H;
 constexpr int TILE_THREADS = 256;
 constexpr int CHUNK = 64;            /* primitives (or vertices) handled by one wave */
 constexpr int MAX_TILES_PER_PRIM = 16; /* primitives touching more tiles go to the pass-wide list */
+enum : uint32_t { CTR_LARGE = 0, CTR_CLIP = 1, CTR_CLIP_TRIS = 2, CTR_OVERFLOW = 3, CTR_COUNT = 4 };
+enum : uint32_t { OVF_LARGE = 1, OVF_CLIP = 2, OVF_CLIP_TRIS = 4 };
 constexpr int MAX_TILE_AXIS = 256;   /* tile coordinates are packed in 8 bits */
 constexpr int SUBPIXEL_BITS = 8;
 constexpr float GUARD_BAND = 2.0f;
@@ -28,6 +30,46 @@ enum : uint32_t {
 };
 
 constexpr uint32_t BBOX_CULLED = 0x000000FFu; /* tx0=255 > tx1=0: nothing to draw */
+
+/* Bits of TileEntry::slot_flags and PrimRec::draw_flags */
+constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   /* primitive slot (submission number) */
+constexpr uint32_t ENTRY_SUB_SHIFT = 28;      /* bits 28..30: fan index of a clipped primitive's triangle */
+constexpr uint32_t FLAG_CLIPPED = 0x80000000u;
+constexpr uint32_t MAX_FAN = 7;               /* a triangle clipped by 6 planes has at most 9 corners */
+
+/* One triangle in a tile's list: 16 bytes, read with one dwordx4 per lane.
+ * Unclipped: a,b,c index svtx[] and are ordered so the area is positive.
+ * Clipped (FLAG_CLIPPED): a indexes clip_tris[]. */
+struct TileEntry {
+    uint32_t a, b, c;
+    uint32_t slot_flags;
+};
+
+/* Entry of the pass-wide list (primitives spanning many tiles, and overflow of full tile lists) */
+struct LargeEntry {
+    TileEntry e;
+    uint32_t box;      /* packed tile box the entry applies to */
+    uint32_t pad[3];
+};
+
+/* Per primitive slot, written by setup for every primitive that survives: what shading needs.
+ * Unclipped: v0..v2 index svtx[] in the primitive's own corner order.
+ * Clipped (FLAG_CLIPPED in draw_flags): v0 = index of its first ClipTri. */
+struct PrimRec {
+    uint32_t v0, v1, v2;
+    uint32_t draw_flags; /* draw index | FLAG_CLIPPED */
+};
+
+/* One fan triangle of a clipped primitive, oriented (positive area), 128 bytes */
+struct ClipTri {
+    int32_t x[3], y[3];
+    float z[3], iw[3];
+    float bary[9];      /* bary[k*3+j]: weight of the parent's corner j at this triangle's corner k */
+    uint32_t v[3];      /* the parent's corners in svtx[] */
+    uint32_t draw;
+    uint32_t valid;     /* 0: degenerate or culled, never rasterised */
+    uint32_t pad[5];
+};
 
 /* Screen-space vertex written by the vertex kernel: 16 bytes, one dwordx4 per corner in setup */
 struct SVtx {
@@ -87,13 +129,15 @@ struct FrameParams {
     const Chunk* tchunks;
     const TexDesc* textures;
     SVtx* svtx;
-    uint32_t* prim_bbox;     /* per primitive slot: packed tile box or BBOX_CULLED */
-    uint32_t* tile_count;    /* per tile */
-    uint32_t* tile_offset;   /* per tile, exclusive scan of tile_count */
-    uint32_t* tile_cursor;   /* per tile */
-    uint32_t* refs;          /* primitive slots grouped by tile */
-    uint32_t* large_list;    /* primitive slots that touch more than MAX_TILES_PER_PRIM tiles */
-    uint32_t* large_count;
+    PrimRec* prim_rec;       /* per primitive slot */
+    uint32_t* tile_count;    /* per tile: entries appended this frame (may exceed tile_capacity) */
+    TileEntry* tile_lists;   /* tile t owns entries [t*tile_capacity, (t+1)*tile_capacity) */
+    LargeEntry* large_list;  /* primitives touching more than MAX_TILES_PER_PRIM tiles + tile-list overflow */
+    uint32_t* clip_list;     /* slots that need the clipper */
+    ClipTri* clip_tris;
+    uint32_t* counters;      /* [0] large_list entries, [1] clip_list entries, [2] clip_tris used, [3] overflow flags */
+    uint32_t* status_host;   /* pinned host word: overflow flags of the last frame that had any */
+    uint32_t tile_capacity, large_capacity, clip_capacity, clip_tri_capacity;
     uint8_t* color;          /* resolved colour, width*height*4 */
     uint32_t* depth;         /* width*height*samples */
     const float* srgb_decode; /* 256 floats */
@@ -123,8 +167,7 @@ void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n
 void launch_constants(const FrameParams& fp, hipStream_t s);
 void launch_vertex(const FrameParams& fp, hipStream_t s);
 void launch_setup(const FrameParams& fp, hipStream_t s);
-void launch_scan(const FrameParams& fp, hipStream_t s);
-void launch_fill(const FrameParams& fp, hipStream_t s);
+void launch_clip(const FrameParams& fp, hipStream_t s);
 void launch_tile(const FrameParams& fp, hipStream_t s);
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
                 const float* srgb_decode, const float* srgb_thr, const uint8_t* srgb_lut, hipStream_t s);

@@ -5,9 +5,10 @@
  *   k_constants  per-draw matrices from the uniform buffer (read at execution time,
  *                base_obj_viewer_app.cpp:134-138) and the push constants
  *   k_vertex     vertex fetch + position shader + clip codes + viewport + 24.8 snap
- *   k_setup      per primitive: reject / cull / tile box, per-tile counts
- *   k_scan       exclusive scan of the tile counts
- *   k_fill       primitive slots grouped by tile
+ *   k_setup      per primitive: reject / cull / orient, then append a 16-byte entry to the
+ *                list of every tile its box touches (one pass, fixed-capacity lists,
+ *                one atomic per wave and tile through ballot + popcount prefix)
+ *   k_clip       the few primitives crossing near/far/guard band: clip, fan, bin
  *   k_tile       one workgroup per 32x32 tile: edge-function rasteriser into an LDS
  *                depth/owner word per sample, then one shading per covered pixel and
  *                coalesced colour/depth stores
@@ -164,131 +165,170 @@ __global__ __launch_bounds__(256) void k_vertex(FrameParams fp)
     fp.svtx[d.svtx_base + v] = out;
 }
 
-/* ------------------------------------------------------------------ setup: tile box per primitive + tile counts */
+/* ------------------------------------------------------------------ setup: cull, orient, bin (one pass) */
 
-/* tile box of everything a primitive rasterises; BBOX_CULLED when nothing */
-__device__ uint32_t prim_tile_box(const FrameParams& fp, const DrawStatic& d, const float* clip_m, uint32_t tri)
+__device__ __forceinline__ void flag_overflow(const FrameParams& fp, uint32_t bit) { atomicOr(&fp.counters[CTR_OVERFLOW], bit); }
+
+/* append to the pass-wide list; one lane at a time */
+__device__ __forceinline__ void push_large(const FrameParams& fp, const TileEntry& e, uint32_t box)
 {
-    PrimFetch pf;
-    if (!fetch_prim(fp, d, tri, pf)) return BBOX_CULLED;
-    int cls = classify_prim(pf);
-    if (cls == 0) return BBOX_CULLED;
-    int bx0 = 1 << 30, by0 = 1 << 30, bx1 = -1, by1 = -1;
-    if (cls == 1) {
-        RTri t;
-        tri_from_fetch(pf, t);
-        if (!setup_tri(t, d.cull_mode, d.front_face)) return BBOX_CULLED;
-        if (!pixel_box(fp, t, bx0, by0, bx1, by1)) return BBOX_CULLED;
-    } else {
-        ClipFan fan;
-        build_clip_fan(fp, d, clip_m, pf.idx[0], pf.idx[1], pf.idx[2], fan);
-        for (int k = 1; k + 1 < fan.n; ++k) {
-            RTri t; float bary[3][3];
-            if (!fan_triangle(fan, k, d.cull_mode, d.front_face, t, bary)) continue;
-            int x0, y0, x1, y1;
-            if (!pixel_box(fp, t, x0, y0, x1, y1)) continue;
-            bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1);
-        }
-        if (bx1 < 0) return BBOX_CULLED;
-    }
-    return pack_bbox(bx0 >> TILE_SHIFT, by0 >> TILE_SHIFT, bx1 >> TILE_SHIFT, by1 >> TILE_SHIFT);
+    uint32_t pos = atomicAdd(&fp.counters[CTR_LARGE], 1u);
+    if (pos >= fp.large_capacity) { flag_overflow(fp, OVF_LARGE); return; }
+    LargeEntry le;
+    le.e = e; le.box = box; le.pad[0] = le.pad[1] = le.pad[2] = 0;
+    fp.large_list[pos] = le;
 }
 
-/* Walks the tiles of every lane's box with wave-uniform control flow.  For tile
- * number k of its box a lane gets a slot from the tile's counter; lanes of the wave
- * that hit the same tile share one atomic. */
-template <bool WRITE>
-__device__ __forceinline__ void bin_wave(const FrameParams& fp, uint32_t box, uint32_t slot)
+/* Appends every lane's entry to the lists of the tiles in its box, with wave-uniform
+ * control flow.  Lanes of the wave that hit the same tile share one atomic: the leader
+ * adds the population count and each lane takes base + its rank among those lanes
+ * (ballot + popcount prefix).  A full tile list spills to the pass-wide list. */
+__device__ __forceinline__ void bin_wave(const FrameParams& fp, bool valid, const TileEntry& e, uint32_t box)
 {
     const uint32_t lane = lane_id();
-    int tx0 = box & 255u, ty0 = (box >> 8) & 255u, tx1 = (box >> 16) & 255u, ty1 = box >> 24;
-    int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;
-    int n = (box == BBOX_CULLED) ? 0 : w * h;
-    bool large = n > MAX_TILES_PER_PRIM;
+    const int tx0 = box & 255u, ty0 = (box >> 8) & 255u, tx1 = (box >> 16) & 255u, ty1 = box >> 24;
+    const int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;
+    int n = valid ? w * h : 0;
+    const bool large = n > MAX_TILES_PER_PRIM;
     if (large) n = 0;
-    uint32_t* counter = WRITE ? fp.tile_cursor : fp.tile_count;
     for (int k = 0;; ++k) {
-        bool act = k < n;
+        const bool act = k < n;
         if (__ballot(act) == 0ull) break;
         int tile = -1;
         if (act) {
-            int ty = ty0 + k / w, tx = tx0 + k % w;
-            int t = ty * (int)fp.tiles_x + tx;
+            const int ty = ty0 + k / w, tx = tx0 + k % w;
+            const int t = ty * (int)fp.tiles_x + tx;
             if ((uint32_t)t % fp.shard_count == fp.shard_index) tile = t;
         }
         uint64_t pending = __ballot(tile >= 0);
         while (pending) {
-            int leader = __ffsll((unsigned long long)pending) - 1;
-            int lt = __shfl(tile, leader);
-            uint64_t same = __ballot(tile == lt);
+            const int leader = __ffsll((unsigned long long)pending) - 1;
+            const int lt = __shfl(tile, leader);
+            const uint64_t same = __ballot(tile == lt);
             uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&counter[lt], (uint32_t)__popcll(same));
-            if (WRITE) {
-                base = (uint32_t)__shfl((int)base, leader);
-                if (tile == lt) {
-                    uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                    fp.refs[fp.tile_offset[lt] + base + rank] = slot;
-                }
+            if ((int)lane == leader) base = atomicAdd(&fp.tile_count[lt], (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (tile == lt) {
+                const uint32_t pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                if (pos < fp.tile_capacity) fp.tile_lists[(size_t)lt * fp.tile_capacity + pos] = e;
+                else push_large(fp, e, pack_bbox(lt % (int)fp.tiles_x, lt / (int)fp.tiles_x, lt % (int)fp.tiles_x, lt / (int)fp.tiles_x));
             }
             pending &= ~same;
         }
     }
-    if (WRITE) {
-        uint64_t lm = __ballot(large);
-        if (lm) {
-            int leader = __ffsll((unsigned long long)lm) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(fp.large_count, (uint32_t)__popcll(lm));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (large) fp.large_list[base + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = slot;
+    if (large) push_large(fp, e, box);
+}
+
+/* same for a single lane (the clip kernel) */
+__device__ __forceinline__ void bin_one(const FrameParams& fp, const TileEntry& e, uint32_t box)
+{
+    const int tx0 = box & 255u, ty0 = (box >> 8) & 255u, tx1 = (box >> 16) & 255u, ty1 = box >> 24;
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MAX_TILES_PER_PRIM) { push_large(fp, e, box); return; }
+    for (int ty = ty0; ty <= ty1; ++ty) {
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const int t = ty * (int)fp.tiles_x + tx;
+            if ((uint32_t)t % fp.shard_count != fp.shard_index) continue;
+            const uint32_t pos = atomicAdd(&fp.tile_count[t], 1u);
+            if (pos < fp.tile_capacity) fp.tile_lists[(size_t)t * fp.tile_capacity + pos] = e;
+            else push_large(fp, e, pack_bbox(tx, ty, tx, ty));
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_setup(FrameParams fp)
 {
-    uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_tchunks) return;
     const Chunk c = fp.tchunks[chunk];
     const DrawStatic& d = fp.draws[c.draw];
-    uint32_t tri = c.first + lane_id();
-    uint32_t slot = chunk * 64u + lane_id();
+    const uint32_t lane = lane_id();
+    const uint32_t tri = c.first + lane;
+    const uint32_t slot = chunk * 64u + lane;
+    bool valid = false, needs_clip = false;
+    TileEntry e = {0, 0, 0, slot};
     uint32_t box = BBOX_CULLED;
-    if (tri < d.tri_count) box = prim_tile_box(fp, d, fp.derived[c.draw].clip_m, tri);
-    fp.prim_bbox[slot] = box;
-    bin_wave<false>(fp, box, slot);
-}
-
-__global__ __launch_bounds__(256) void k_fill(FrameParams fp)
-{
-    uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (chunk >= fp.n_tchunks) return;
-    uint32_t slot = chunk * 64u + lane_id();
-    bin_wave<true>(fp, fp.prim_bbox[slot], slot);
-}
-
-/* exclusive scan of tile_count into tile_offset by one workgroup; clears the cursors */
-__global__ __launch_bounds__(1024) void k_scan(FrameParams fp)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t n = fp.tiles_x * fp.tiles_y;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per, e = min(b + per, n);
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; ++i) sum += fp.tile_count[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    PrimFetch pf;
+    if (tri < d.tri_count && fetch_prim(fp, d, tri, pf)) {
+        const int cls = classify_prim(pf);
+        if (cls == 2) {
+            needs_clip = true;
+        } else if (cls == 1) {
+            RTri t;
+            tri_from_fetch(pf, t);
+            int x0, y0, x1, y1;
+            if (setup_tri(t, d.cull_mode, d.front_face) && pixel_box(fp, t, x0, y0, x1, y1)) {
+                valid = true;
+                box = pack_bbox(x0 >> TILE_SHIFT, y0 >> TILE_SHIFT, x1 >> TILE_SHIFT, y1 >> TILE_SHIFT);
+                const uint32_t v0 = d.svtx_base + pf.idx[0], v1 = d.svtx_base + pf.idx[1], v2 = d.svtx_base + pf.idx[2];
+                /* what shading needs, in the primitive's own corner order */
+                PrimRec pr = {v0, v1, v2, c.draw};
+                fp.prim_rec[slot] = pr;
+                /* what rasterisation needs: corners ordered for positive area */
+                e.a = d.svtx_base + pf.idx[t.corner[0]];
+                e.b = d.svtx_base + pf.idx[t.corner[1]];
+                e.c = d.svtx_base + pf.idx[t.corner[2]];
+            }
+        }
     }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = b; i < e; ++i) {
-        fp.tile_offset[i] = run;
-        run += fp.tile_count[i];
-        fp.tile_cursor[i] = 0;
+    /* primitives for the clipper: one atomic per wave, slots stored in lane order */
+    const uint64_t cm = __ballot(needs_clip);
+    if (cm) {
+        const int leader = __ffsll((unsigned long long)cm) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&fp.counters[CTR_CLIP], (uint32_t)__popcll(cm));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (needs_clip) {
+            const uint32_t pos = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+            if (pos < fp.clip_capacity) fp.clip_list[pos] = slot;
+            else flag_overflow(fp, OVF_CLIP);
+        }
+    }
+    bin_wave(fp, valid, e, box);
+}
+
+/* ------------------------------------------------------------------ clipper: one lane per primitive that crosses
+ * the near plane, the far plane or the guard band.  Kept out of the setup and tile kernels so
+ * those carry no scratch memory. */
+
+__global__ __launch_bounds__(64) void k_clip(FrameParams fp)
+{
+    const uint32_t n = min(fp.counters[CTR_CLIP], fp.clip_capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = fp.clip_list[i];
+        uint32_t draw, tri;
+        slot_to_prim(fp, slot, draw, tri);
+        const DrawStatic& d = fp.draws[draw];
+        const uint32_t* ip = d.ib + (size_t)tri * 3;
+        const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+        ClipFan fan;
+        build_clip_fan(fp, d, fp.derived[draw].clip_m, i0, i1, i2, fan);
+        if (fan.n < 3) continue;
+        const uint32_t count = (uint32_t)fan.n - 2u;
+        const uint32_t first = atomicAdd(&fp.counters[CTR_CLIP_TRIS], count);
+        if (first + count > fp.clip_tri_capacity) { flag_overflow(fp, OVF_CLIP_TRIS); continue; }
+        PrimRec pr = {first, 0u, 0u, draw | FLAG_CLIPPED};
+        fp.prim_rec[slot] = pr;
+        for (int k = 1; k + 1 < fan.n; ++k) {
+            RTri t; float bary[3][3];
+            ClipTri ct;
+            const bool ok = fan_triangle(fan, k, d.cull_mode, d.front_face, t, bary);
+            int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+            const bool vis = ok && pixel_box(fp, t, x0, y0, x1, y1);
+            for (int q = 0; q < 3; ++q) {
+                ct.x[q] = t.x[q]; ct.y[q] = t.y[q]; ct.z[q] = t.z[q]; ct.iw[q] = t.iw[q];
+                for (int j = 0; j < 3; ++j) ct.bary[q * 3 + j] = ok ? bary[q][j] : 0.0f;
+            }
+            ct.v[0] = d.svtx_base + i0; ct.v[1] = d.svtx_base + i1; ct.v[2] = d.svtx_base + i2;
+            ct.draw = draw;
+            ct.valid = vis ? 1u : 0u;
+            for (int j = 0; j < 5; ++j) ct.pad[j] = 0;
+            const uint32_t idx = first + (uint32_t)(k - 1);
+            fp.clip_tris[idx] = ct;
+            if (vis) {
+                TileEntry e = {idx, 0u, 0u, slot | ((uint32_t)(k - 1) << ENTRY_SUB_SHIFT) | FLAG_CLIPPED};
+                bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, y0 >> TILE_SHIFT, x1 >> TILE_SHIFT, y1 >> TILE_SHIFT));
+            }
+        }
     }
 }
 
@@ -298,90 +338,167 @@ __constant__ int c_sample_x4[4] = {96, 224, 32, 160}; /* (0.375,0.125) (0.875,0.
 __constant__ int c_sample_y4[4] = {32, 96, 160, 224};
 
 struct TileCtx {
-    int px0, py0;         /* first pixel of the tile */
+    int px0, py0;           /* first pixel of the tile */
     int rx0, ry0, rx1, ry1; /* inclusive pixel rectangle: tile ∩ clamp */
     unsigned long long* keys;
-    uint32_t samples;
 };
 
-/* Rasterise one oriented triangle into the tile.  I is int32_t when every edge
- * product fits 32 bits (extent below 64 pixels), else int64_t; both give the same
- * integers. */
-template <typename I>
-__device__ __forceinline__ void raster_tri(const FrameParams& fp, const TileCtx& tc, const RTri& t, uint64_t payload)
+/* A triangle as the rasteriser uses it: corners ordered for positive area */
+struct RasterTri {
+    int32_t x[3], y[3];
+    float z[3];
+    uint32_t payload_lo; /* bits 0..7 fan index; the order word is added per depth mode */
+    uint32_t slot;
+};
+
+/* Per-sample test + depth + LDS min for one pixel.  I is int32_t when every edge product
+ * fits 32 bits (extent below 64 pixels), else int64_t; both give the same integers. */
+template <typename I, int S>
+struct EdgeSetup {
+    I ax0, ay0, ax1, ay1, ax2, ay2;
+    I dx0, dy0, dx1, dy1, dx2, dy2;
+    I bias0, bias1, bias2;
+    float z0, dz1, dz2, inv_area;
+    unsigned long long payload;
+    uint32_t depth_test;
+
+    __device__ __forceinline__ void init(const FrameParams& fp, const RasterTri& t)
+    {
+        /* edge k is opposite corner k: e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 */
+        ax0 = t.x[1]; ay0 = t.y[1]; ax1 = t.x[2]; ay1 = t.y[2]; ax2 = t.x[0]; ay2 = t.y[0];
+        dx0 = (I)t.x[2] - (I)t.x[1]; dy0 = (I)t.y[2] - (I)t.y[1];
+        dx1 = (I)t.x[0] - (I)t.x[2]; dy1 = (I)t.y[0] - (I)t.y[2];
+        dx2 = (I)t.x[1] - (I)t.x[0]; dy2 = (I)t.y[1] - (I)t.y[0];
+        /* a point on an edge is inside only if the edge owns it: a bias of -1 otherwise */
+        bias0 = owns_edge(t.x[1], t.y[1], t.x[2], t.y[2]) ? 0 : 1;
+        bias1 = owns_edge(t.x[2], t.y[2], t.x[0], t.y[0]) ? 0 : 1;
+        bias2 = owns_edge(t.x[0], t.y[0], t.x[1], t.y[1]) ? 0 : 1;
+        const int64_t area2 = edge64(t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2]);
+        inv_area = 1.0f / (float)area2;
+        z0 = t.z[0]; dz1 = t.z[1] - t.z[0]; dz2 = t.z[2] - t.z[0];
+        const uint32_t ord = fp.depth_less ? t.slot : ~t.slot;
+        payload = ((unsigned long long)ord << 8) | (unsigned long long)t.payload_lo;
+        depth_test = fp.depth_test;
+    }
+
+    __device__ __forceinline__ void pixel(const TileCtx& tc, int x, int y) const
+    {
+        const uint32_t pix = (uint32_t)((y - tc.py0) * TILE_W + (x - tc.px0));
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const I px = (I)(x * 256 + (S == 1 ? 128 : c_sample_x4[s]));
+            const I py = (I)(y * 256 + (S == 1 ? 128 : c_sample_y4[s]));
+            const I e0 = dx0 * (py - ay0) - dy0 * (px - ax0);
+            const I e1 = dx1 * (py - ay1) - dy1 * (px - ax1);
+            const I e2 = dx2 * (py - ay2) - dy2 * (px - ax2);
+            if (((e0 - bias0) | (e1 - bias1) | (e2 - bias2)) < 0) continue;
+            const float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
+            const float z = fma32(b2, dz2, fma32(b1, dz1, z0));
+            const uint32_t d24 = depth_test ? depth24(z) : 0u;
+            const unsigned long long key = ((unsigned long long)d24 << 40) | payload;
+            unsigned long long* word = &tc.keys[pix * S + s];
+            if (key < *word) atomicMin(word, key); /* early depth test: read, then the LDS atomic */
+        }
+    }
+};
+
+__device__ __forceinline__ bool tri_box_in_tile(const FrameParams& fp, const TileCtx& tc, const RasterTri& t,
+                                                int& x0, int& y0, int& x1, int& y1)
 {
-    int x0, y0, x1, y1;
-    if (!pixel_box(fp, t, x0, y0, x1, y1)) return;
+    const int minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
+    const int miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
+    if (fp.samples == 1) { x0 = (minx + 127) >> 8; x1 = (maxx - 128) >> 8; y0 = (miny + 127) >> 8; y1 = (maxy - 128) >> 8; }
+    else { x0 = minx >> 8; x1 = maxx >> 8; y0 = miny >> 8; y1 = maxy >> 8; }
     x0 = max(x0, tc.rx0); y0 = max(y0, tc.ry0); x1 = min(x1, tc.rx1); y1 = min(y1, tc.ry1);
-    if (x0 > x1 || y0 > y1) return;
-    /* edge k is opposite corner k: e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 */
-    const I ax0 = t.x[1], ay0 = t.y[1], bx0 = t.x[2], by0 = t.y[2];
-    const I ax1 = t.x[2], ay1 = t.y[2], bx1 = t.x[0], by1 = t.y[0];
-    const I ax2 = t.x[0], ay2 = t.y[0], bx2 = t.x[1], by2 = t.y[1];
-    const I dx0 = bx0 - ax0, dy0 = by0 - ay0, dx1 = bx1 - ax1, dy1 = by1 - ay1, dx2 = bx2 - ax2, dy2 = by2 - ay2;
-    /* a point on an edge is inside only if the edge owns it: fold that into a bias of -1 */
-    const I bias0 = owns_edge(t.x[1], t.y[1], t.x[2], t.y[2]) ? 0 : 1;
-    const I bias1 = owns_edge(t.x[2], t.y[2], t.x[0], t.y[0]) ? 0 : 1;
-    const I bias2 = owns_edge(t.x[0], t.y[0], t.x[1], t.y[1]) ? 0 : 1;
-    const float dz1 = t.z[1] - t.z[0], dz2 = t.z[2] - t.z[0];
-    const uint32_t S = tc.samples;
-    for (int y = y0; y <= y1; ++y) {
-        for (int x = x0; x <= x1; ++x) {
-            const uint32_t pix = (uint32_t)((y - tc.py0) * TILE_W + (x - tc.px0));
-            for (uint32_t s = 0; s < S; ++s) {
-                const I px = (I)(x * 256 + (S == 1 ? 128 : c_sample_x4[s]));
-                const I py = (I)(y * 256 + (S == 1 ? 128 : c_sample_y4[s]));
-                const I e0 = dx0 * (py - ay0) - dy0 * (px - ax0);
-                const I e1 = dx1 * (py - ay1) - dy1 * (px - ax1);
-                const I e2 = dx2 * (py - ay2) - dy2 * (px - ax2);
-                if (((e0 - bias0) | (e1 - bias1) | (e2 - bias2)) < 0) continue;
-                const float b1 = (float)e1 * t.inv_area, b2 = (float)e2 * t.inv_area;
-                const float z = fma32(b2, dz2, fma32(b1, dz1, t.z[0]));
-                const uint32_t d24 = fp.depth_test ? depth24(z) : 0u;
-                const unsigned long long key = ((unsigned long long)d24 << 40) | payload;
-                unsigned long long* slot = &tc.keys[pix * S + s];
-                if (key < *slot) atomicMin(slot, key); /* early-out read, then the LDS atomic */
-            }
+    return x0 <= x1 && y0 <= y1;
+}
+
+__device__ __forceinline__ bool tri_is_small(const RasterTri& t)
+{
+    const int ext = max(max(t.x[0], max(t.x[1], t.x[2])) - min(t.x[0], min(t.x[1], t.x[2])),
+                        max(t.y[0], max(t.y[1], t.y[2])) - min(t.y[0], min(t.y[1], t.y[2])));
+    return ext < (1 << 14);
+}
+
+/* one lane walks its own triangle's box */
+template <int S>
+__device__ __forceinline__ void raster_lane(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int x1, int y1)
+{
+    if (tri_is_small(t)) {
+        EdgeSetup<int32_t, S> es;
+        es.init(fp, t);
+        for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) es.pixel(tc, x, y);
+    } else {
+        EdgeSetup<int64_t, S> es;
+        es.init(fp, t);
+        for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) es.pixel(tc, x, y);
+    }
+}
+
+/* the whole wave walks one triangle's box in 8x8 pixel blocks (t and the box are wave-uniform) */
+template <int S>
+__device__ __forceinline__ void raster_wave(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int x1, int y1)
+{
+    const int lx = (int)(lane_id() & 7u), ly = (int)(lane_id() >> 3);
+    if (tri_is_small(t)) {
+        EdgeSetup<int32_t, S> es;
+        es.init(fp, t);
+        for (int by = y0; by <= y1; by += 8) for (int bx = x0; bx <= x1; bx += 8) {
+            const int x = bx + lx, y = by + ly;
+            if (x <= x1 && y <= y1) es.pixel(tc, x, y);
+        }
+    } else {
+        EdgeSetup<int64_t, S> es;
+        es.init(fp, t);
+        for (int by = y0; by <= y1; by += 8) for (int bx = x0; bx <= x1; bx += 8) {
+            const int x = bx + lx, y = by + ly;
+            if (x <= x1 && y <= y1) es.pixel(tc, x, y);
         }
     }
 }
 
-__device__ __forceinline__ void raster_any(const FrameParams& fp, const TileCtx& tc, const RTri& t, uint64_t payload)
+/* entry -> triangle; false when the entry must not be drawn */
+__device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const TileEntry& e, RasterTri& t)
 {
-    int ext = max(max(t.x[0], max(t.x[1], t.x[2])) - min(t.x[0], min(t.x[1], t.x[2])),
-                  max(t.y[0], max(t.y[1], t.y[2])) - min(t.y[0], min(t.y[1], t.y[2])));
-    if (ext < (1 << 14)) raster_tri<int32_t>(fp, tc, t, payload);
-    else raster_tri<int64_t>(fp, tc, t, payload);
+    t.slot = e.slot_flags & SLOT_MASK;
+    if (e.slot_flags & FLAG_CLIPPED) {
+        const ClipTri* ct = &fp.clip_tris[e.a];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t.x[k] = ct->x[k]; t.y[k] = ct->y[k]; t.z[k] = ct->z[k]; }
+        t.payload_lo = (e.slot_flags >> ENTRY_SUB_SHIFT) & 7u;
+        return true;
+    }
+    const SVtx a = fp.svtx[e.a], b = fp.svtx[e.b], c = fp.svtx[e.c];
+    t.x[0] = a.xf >> 8; t.y[0] = a.y; t.z[0] = a.z;
+    t.x[1] = b.xf >> 8; t.y[1] = b.y; t.z[1] = b.z;
+    t.x[2] = c.xf >> 8; t.y[2] = c.y; t.z[2] = c.z;
+    t.payload_lo = 0;
+    return true;
 }
 
-/* low 40 bits of a fragment's word: submission order (inverted unless LESS) and fan index */
-__device__ __forceinline__ uint64_t make_payload(const FrameParams& fp, uint32_t slot, uint32_t sub)
-{
-    uint32_t ord = fp.depth_less ? slot : ~slot;
-    return ((uint64_t)ord << 8) | (uint64_t)sub;
-}
+constexpr int LANE_RASTER_MAX_PIXELS = 16; /* larger boxes are walked by the whole wave */
 
-__device__ void raster_slot(const FrameParams& fp, const TileCtx& tc, uint32_t slot)
+/* One batch: every lane holds (at most) one triangle.  Small boxes are walked by their own lane;
+ * the others are taken one at a time by the whole wave (ballot, broadcast, 8x8 blocks). */
+template <int S>
+__device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCtx& tc, bool have, const RasterTri& t)
 {
-    uint32_t draw, tri;
-    slot_to_prim(fp, slot, draw, tri);
-    const DrawStatic& d = fp.draws[draw];
-    PrimFetch pf;
-    if (!fetch_prim(fp, d, tri, pf)) return;
-    int cls = classify_prim(pf);
-    if (cls == 1) {
-        RTri t;
-        tri_from_fetch(pf, t);
-        if (!setup_tri(t, d.cull_mode, d.front_face)) return;
-        raster_any(fp, tc, t, make_payload(fp, slot, 0));
-    } else if (cls == 2) {
-        ClipFan fan;
-        build_clip_fan(fp, d, fp.derived[draw].clip_m, pf.idx[0], pf.idx[1], pf.idx[2], fan);
-        for (int k = 1; k + 1 < fan.n; ++k) {
-            RTri t; float bary[3][3];
-            if (!fan_triangle(fan, k, d.cull_mode, d.front_face, t, bary)) continue;
-            raster_any(fp, tc, t, make_payload(fp, slot, (uint32_t)(k - 1)));
+    int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+    const bool hit = have && tri_box_in_tile(fp, tc, t, x0, y0, x1, y1);
+    const int area = hit ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
+    if (hit && area <= LANE_RASTER_MAX_PIXELS) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
+    uint64_t big = __ballot(hit && area > LANE_RASTER_MAX_PIXELS);
+    while (big) {
+        const int src = __ffsll((unsigned long long)big) - 1;
+        big &= big - 1;
+        RasterTri u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u.x[k] = __shfl(t.x[k], src); u.y[k] = __shfl(t.y[k], src); u.z[k] = __shfl(t.z[k], src);
         }
+        u.payload_lo = (uint32_t)__shfl((int)t.payload_lo, src);
+        u.slot = (uint32_t)__shfl((int)t.slot, src);
+        raster_wave<S>(fp, tc, u, __shfl(x0, src), __shfl(y0, src), __shfl(x1, src), __shfl(y1, src));
     }
 }
 
@@ -513,27 +630,38 @@ __device__ void sample_texture(const ShadeTables& tb, const TexDesc& t, float u,
 /* colour of the fragment of (slot, sub) at pixel (x, y) */
 __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, uint32_t slot, uint32_t sub, int x, int y, float* rgba)
 {
-    uint32_t draw, tri;
-    slot_to_prim(fp, slot, draw, tri);
-    const DrawStatic& d = fp.draws[draw];
-    const DrawDerived& dd = fp.derived[draw];
-    PrimFetch pf;
-    fetch_prim(fp, d, tri, pf);
+    const PrimRec pr = fp.prim_rec[slot];
+    const bool clipped = (pr.draw_flags & FLAG_CLIPPED) != 0u;
     RTri t;
     float bary[3][3];
-    bool clipped = classify_prim(pf) == 2;
+    uint32_t vtx[3];
+    uint32_t draw;
     if (!clipped) {
-        tri_from_fetch(pf, t);
-        setup_tri(t, d.cull_mode, d.front_face);
+        draw = pr.draw_flags & SLOT_MASK;
+        vtx[0] = pr.v0; vtx[1] = pr.v1; vtx[2] = pr.v2;
+        const SVtx a = fp.svtx[pr.v0], b = fp.svtx[pr.v1], c = fp.svtx[pr.v2];
+        t.x[0] = a.xf >> 8; t.y[0] = a.y; t.z[0] = a.z; t.iw[0] = a.iw; t.corner[0] = 0;
+        t.x[1] = b.xf >> 8; t.y[1] = b.y; t.z[1] = b.z; t.iw[1] = b.iw; t.corner[1] = 1;
+        t.x[2] = c.xf >> 8; t.y[2] = c.y; t.z[2] = c.z; t.iw[2] = c.iw; t.corner[2] = 2;
+        setup_tri(t, 0u, 0u); /* orientation only: the primitive already passed culling */
     } else {
-        ClipFan fan;
-        build_clip_fan(fp, d, dd.clip_m, pf.idx[0], pf.idx[1], pf.idx[2], fan);
-        fan_triangle(fan, (int)sub + 1, d.cull_mode, d.front_face, t, bary);
+        const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
+        draw = ct->draw;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            t.x[k] = ct->x[k]; t.y[k] = ct->y[k]; t.z[k] = ct->z[k]; t.iw[k] = ct->iw[k]; t.corner[k] = (uint8_t)k;
+            bary[k][0] = ct->bary[k * 3 + 0]; bary[k][1] = ct->bary[k * 3 + 1]; bary[k][2] = ct->bary[k * 3 + 2];
+            vtx[k] = ct->v[k];
+        }
+        t.area2 = edge64(t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2]);
+        t.inv_area = 1.0f / (float)t.area2;
     }
+    const DrawStatic& d = fp.draws[draw];
+    const DrawDerived& dd = fp.derived[draw];
     Varyings v0, v1, v2;
-    vs_varyings(d, dd.nrm_m, pf.idx[0], v0);
-    vs_varyings(d, dd.nrm_m, pf.idx[1], v1);
-    vs_varyings(d, dd.nrm_m, pf.idx[2], v2);
+    vs_varyings(d, dd.nrm_m, vtx[0] - d.svtx_base, v0);
+    vs_varyings(d, dd.nrm_m, vtx[1] - d.svtx_base, v1);
+    vs_varyings(d, dd.nrm_m, vtx[2] - d.svtx_base, v2);
     const int64_t px = (int64_t)x * 256 + 128, py = (int64_t)y * 256 + 128;
     float lam[3];
     parent_weights(t, clipped, bary, px, py, lam);
@@ -590,7 +718,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
     tc.rx0 = max(tc.px0, fp.clamp_x0); tc.ry0 = max(tc.py0, fp.clamp_y0);
     tc.rx1 = min(tc.px0 + TILE_W - 1, fp.clamp_x1); tc.ry1 = min(tc.py0 + TILE_H - 1, fp.clamp_y1);
     tc.keys = keys;
-    tc.samples = S;
 
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
@@ -601,16 +728,34 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
     __syncthreads();
 
     if (tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1) {
-        const uint32_t first = fp.tile_offset[tile], count = fp.tile_count[tile];
-        for (uint32_t i = threadIdx.x; i < count; i += TILE_THREADS) raster_slot(fp, tc, fp.refs[first + i]);
-        const uint32_t n_large = *fp.large_count;
-        for (uint32_t i = threadIdx.x; i < n_large; i += TILE_THREADS) {
-            const uint32_t slot = fp.large_list[i];
-            const uint32_t box = fp.prim_bbox[slot];
-            const int bx0 = box & 255u, by0 = (box >> 8) & 255u, bx1 = (box >> 16) & 255u, by1 = box >> 24;
-            if (tx < bx0 || tx > bx1 || ty < by0 || ty > by1) continue;
-            raster_slot(fp, tc, slot);
+        /* this tile's list: 16-byte entries, one per lane per batch */
+        const uint32_t count = min(fp.tile_count[tile], fp.tile_capacity);
+        const TileEntry* list = fp.tile_lists + (size_t)tile * fp.tile_capacity;
+        for (uint32_t base = 0; base < count; base += TILE_THREADS) {
+            const uint32_t i = base + threadIdx.x;
+            RasterTri t;
+            bool have = i < count;
+            if (have) have = load_raster_tri(fp, list[i], t);
+            raster_batch<S>(fp, tc, have, t);
         }
+        /* the pass-wide list: primitives spanning many tiles, and spill of full tile lists */
+        const uint32_t n_large = min(fp.counters[CTR_LARGE], fp.large_capacity);
+        for (uint32_t base = 0; base < n_large; base += TILE_THREADS) {
+            const uint32_t i = base + threadIdx.x;
+            RasterTri t;
+            bool have = i < n_large;
+            if (have) {
+                const LargeEntry le = fp.large_list[i];
+                const int bx0 = le.box & 255u, by0 = (le.box >> 8) & 255u, bx1 = (le.box >> 16) & 255u, by1 = le.box >> 24;
+                have = tx >= bx0 && tx <= bx1 && ty >= by0 && ty <= by1;
+                if (have) have = load_raster_tri(fp, le.e, t);
+            }
+            raster_batch<S>(fp, tc, have, t);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t ovf = fp.counters[CTR_OVERFLOW];
+        if (ovf) *fp.status_host = ovf; /* a list overflowed: the host reports it at the next wait */
     }
     __syncthreads();
 
@@ -723,15 +868,10 @@ void launch_setup(const FrameParams& fp, hipStream_t s)
     hipLaunchKernelGGL(k_setup, dim3((fp.n_tchunks + 3) / 4), dim3(256), 0, s, fp);
 }
 
-void launch_scan(const FrameParams& fp, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, fp);
-}
-
-void launch_fill(const FrameParams& fp, hipStream_t s)
+void launch_clip(const FrameParams& fp, hipStream_t s)
 {
     if (!fp.n_tchunks) return;
-    hipLaunchKernelGGL(k_fill, dim3((fp.n_tchunks + 3) / 4), dim3(256), 0, s, fp);
+    hipLaunchKernelGGL(k_clip, dim3(256), dim3(64), 0, s, fp);
 }
 
 void launch_tile(const FrameParams& fp, hipStream_t s)
