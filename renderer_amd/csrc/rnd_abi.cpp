@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -65,9 +66,7 @@ struct rnd_device_t {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    float* srgb_decode = nullptr;
-    float* srgb_thr = nullptr;
-    uint8_t* srgb_lut = nullptr;
+    ShadeTables* tables = nullptr; /* sRGB decode/encode tables in device memory */
     /* pinned ring for small host->device writes (the per-frame uniform block): the copy is
      * queued on the stream and the call returns without waiting for the device */
     static constexpr int STAGE_SLOTS = 64;
@@ -104,6 +103,7 @@ struct rnd_target_t {
     int32_t color_format;
     uint8_t* color;
     uint32_t* depth;
+    uint32_t* vis; /* owning primitive per sample, handed from the tile kernel to the shading kernel */
 };
 
 struct rnd_pipeline_t {
@@ -160,6 +160,7 @@ struct rnd_cmd_t {
     DeviceArray<Chunk> d_vchunks, d_tchunks;
     DeviceArray<TexDesc> d_textures;
     DeviceArray<SVtx> d_svtx;
+    DeviceArray<float4> d_svary;
     DeviceArray<PrimRec> d_prim_rec;
     DeviceArray<TileEntry> d_tile_lists;
     DeviceArray<LargeEntry> d_large_list;
@@ -171,7 +172,7 @@ struct rnd_cmd_t {
     void release_compiled()
     {
         d_draws.release(); d_derived.release(); d_vchunks.release(); d_tchunks.release(); d_textures.release();
-        d_svtx.release(); d_prim_rec.release(); d_tile_lists.release(); d_large_list.release(); d_clip_tris.release();
+        d_svtx.release(); d_svary.release(); d_prim_rec.release(); d_tile_lists.release(); d_large_list.release(); d_clip_tris.release();
         d_tile_count.release(); d_clip_list.release(); d_counters.release();
     }
 };
@@ -189,7 +190,7 @@ int report_overflow(rnd_device dev)
 {
     if (!dev->status_host || !*dev->status_host) return RND_SUCCESS;
     const uint32_t ovf = *dev->status_host;
-    *dev->status_host = 0;
+    memset(dev->status_host, 0, 64);
     return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, std::string("a work list overflowed while rendering (flags ") + std::to_string(ovf) +
                 "; pass-wide list=1, clip list=2, clipped triangles=4): the frame is incomplete");
 }
@@ -290,32 +291,30 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
     }
     /* sRGB tables: decode[k] = linear value of code k; thr[k] = linear value of code k-0.5;
      * lut[bucket] = number of thresholds <= the bucket's lower edge */
-    std::vector<float> decode(256), thr(257);
-    std::vector<uint8_t> lut(SRGB_LUT_SIZE);
-    for (int k = 0; k < 256; ++k) decode[(size_t)k] = (float)srgb_to_linear(k / 255.0);
-    thr[0] = -INFINITY;
-    for (int k = 1; k < 256; ++k) thr[(size_t)k] = (float)srgb_to_linear((k - 0.5) / 255.0);
-    thr[256] = INFINITY;
+    ShadeTables host_tables;
+    memset(&host_tables, 0, sizeof(host_tables));
+    for (int k = 0; k < 256; ++k) host_tables.decode[k] = (float)srgb_to_linear(k / 255.0);
+    host_tables.thr[0] = -INFINITY;
+    for (int k = 1; k < 256; ++k) host_tables.thr[k] = (float)srgb_to_linear((k - 0.5) / 255.0);
+    host_tables.thr[256] = INFINITY;
     for (uint32_t i = 0; i < SRGB_LUT_SIZE; ++i) {
         uint32_t bits = (i + SRGB_LUT_FIRST) << 16;
         float c;
         memcpy(&c, &bits, 4);
         uint32_t k = 0;
-        while (k < 255 && thr[k + 1] <= c) ++k;
-        lut[i] = (uint8_t)k;
+        while (k < 255 && host_tables.thr[k + 1] <= c) ++k;
+        host_tables.lut[i] = (uint8_t)k;
     }
-    hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&dev->srgb_decode), 256 * 4);
-    hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&dev->srgb_thr), 257 * 4);
-    hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&dev->srgb_lut), SRGB_LUT_SIZE);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { rnd_device_destroy(dev); return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc tables failed"); }
-    HIP_TRY(hipMemcpy(dev->srgb_decode, decode.data(), 256 * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dev->srgb_thr, thr.data(), 257 * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dev->srgb_lut, lut.data(), SRGB_LUT_SIZE, hipMemcpyHostToDevice));
+    if (hipMalloc(reinterpret_cast<void**>(&dev->tables), sizeof(ShadeTables)) != hipSuccess) {
+        rnd_device_destroy(dev);
+        return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc tables failed");
+    }
+    HIP_TRY(hipMemcpy(dev->tables, &host_tables, sizeof(ShadeTables), hipMemcpyHostToDevice));
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) HIP_TRY(hipEventCreate(&dev->ev[i]));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->stage_host), rnd_device_t::STAGE_SLOTS * rnd_device_t::STAGE_SLOT_BYTES, hipHostMallocDefault));
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&dev->stage_ev[i], hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->status_host), 64, hipHostMallocDefault));
-    *dev->status_host = 0;
+    memset(dev->status_host, 0, 64);
     *out = dev;
     return RND_SUCCESS;
 }
@@ -325,9 +324,7 @@ int rnd_device_destroy(rnd_device dev)
     if (!dev) return RND_SUCCESS;
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
-    if (dev->srgb_decode) (void)hipFree(dev->srgb_decode);
-    if (dev->srgb_thr) (void)hipFree(dev->srgb_thr);
-    if (dev->srgb_lut) (void)hipFree(dev->srgb_lut);
+    if (dev->tables) (void)hipFree(dev->tables);
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) if (dev->ev[i]) (void)hipEventDestroy(dev->ev[i]);
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) if (dev->stage_ev[i]) (void)hipEventDestroy(dev->stage_ev[i]);
     if (dev->stage_host) (void)hipHostFree(dev->stage_host);
@@ -458,7 +455,7 @@ int rnd_texture_create_2d(rnd_device dev, uint32_t width, uint32_t height, int32
     if (e != hipSuccess) { rnd_texture_destroy(t); return fail(RND_ERROR_DEVICE_LOST, "texture upload failed"); }
     for (uint32_t l = 1; l < levels; ++l) {
         launch_mip(t->level_ptr[l - 1], level_dim(width, l - 1), level_dim(height, l - 1), t->level_ptr[l], level_dim(width, l),
-                   level_dim(height, l), (int)t->srgb, dev->srgb_decode, dev->srgb_thr, dev->srgb_lut, dev->stream);
+                   level_dim(height, l), (int)t->srgb, dev->tables, dev->stream);
     }
     e = hipStreamSynchronize(dev->stream); /* the reference waits on a fence here (tools.cpp:776-778) */
     if (e != hipSuccess) { rnd_texture_destroy(t); return fail(RND_ERROR_DEVICE_LOST, std::string("mip generation failed: ") + hipGetErrorString(e)); }
@@ -529,10 +526,11 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
     if (depth_format != RND_FORMAT_D24_UNORM_S8_UINT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "depth format must be D24_UNORM_S8_UINT");
     if (samples != 1 && samples != 4) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "sample count must be 1 or 4");
     if (int r = set_device(dev)) return r;
-    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr};
+    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, nullptr};
     size_t px = (size_t)width * height;
     hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&t->color), px * 4);
     hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&t->depth), px * samples * 4);
+    if (e2 == hipSuccess) e2 = hipMalloc(reinterpret_cast<void**>(&t->vis), px * samples * 4);
     if (e1 != hipSuccess || e2 != hipSuccess) { rnd_target_destroy(t); return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc target failed"); }
     (void)hipMemset(t->color, 0, px * 4);
     (void)hipMemset(t->depth, 0, px * samples * 4);
@@ -568,6 +566,7 @@ int rnd_target_destroy(rnd_target target)
     (void)hipStreamSynchronize(target->dev->stream);
     if (target->color) (void)hipFree(target->color);
     if (target->depth) (void)hipFree(target->depth);
+    if (target->vis) (void)hipFree(target->vis);
     delete target;
     return RND_SUCCESS;
 }
@@ -902,8 +901,9 @@ int rnd_cmd_end(rnd_cmd cmd)
     HIP_TRY(cmd->d_tchunks.upload(tchunks));
     HIP_TRY(cmd->d_textures.upload(td));
     HIP_TRY(cmd->d_svtx.resize((size_t)svtx_total));
+    HIP_TRY(cmd->d_svary.resize((size_t)svtx_total));
     HIP_TRY(cmd->d_prim_rec.resize(slots));
-    HIP_TRY(cmd->d_tile_count.resize(n_tiles));
+    HIP_TRY(cmd->d_tile_count.resize(n_tiles * TILE_COUNT_STRIDE));
     HIP_TRY(cmd->d_tile_lists.resize(n_tiles * tile_cap));
     HIP_TRY(cmd->d_large_list.resize(large_cap));
     HIP_TRY(cmd->d_clip_list.resize(clip_cap));
@@ -914,7 +914,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     memset(&fp, 0, sizeof(fp));
     fp.draws = cmd->d_draws.ptr; fp.derived = cmd->d_derived.ptr;
     fp.vchunks = cmd->d_vchunks.ptr; fp.tchunks = cmd->d_tchunks.ptr; fp.textures = cmd->d_textures.ptr;
-    fp.svtx = cmd->d_svtx.ptr; fp.prim_rec = cmd->d_prim_rec.ptr;
+    fp.svtx = cmd->d_svtx.ptr; fp.svary = cmd->d_svary.ptr; fp.prim_rec = cmd->d_prim_rec.ptr;
     fp.tile_count = cmd->d_tile_count.ptr; fp.tile_lists = cmd->d_tile_lists.ptr;
     fp.large_list = cmd->d_large_list.ptr; fp.clip_list = cmd->d_clip_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
     fp.counters = cmd->d_counters.ptr;
@@ -926,7 +926,7 @@ int rnd_cmd_end(rnd_cmd cmd)
         fp.status_host = static_cast<uint32_t*>(dp);
     }
     fp.color = tg->color; fp.depth = tg->depth;
-    fp.srgb_decode = dev->srgb_decode; fp.srgb_thr = dev->srgb_thr; fp.srgb_lut = dev->srgb_lut;
+    fp.vis = tg->vis; fp.tables = dev->tables;
     fp.n_draws = (uint32_t)n; fp.n_vchunks = (uint32_t)vchunks.size(); fp.n_tchunks = (uint32_t)tchunks.size();
     fp.n_textures = (uint32_t)td.size();
     fp.width = tg->width; fp.height = tg->height; fp.samples = tg->samples;
@@ -981,11 +981,9 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     if (int r = set_device(dev)) return r;
     FrameParams fp = cmd->fp;
     fp.shard_index = cmd->shard_index; fp.shard_count = cmd->shard_count;
+    { const char* dbg = getenv("RND_DEBUG"); fp.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u; }
     hipStream_t s = dev->stream;
-    const size_t n_tiles = (size_t)fp.tiles_x * fp.tiles_y;
     const bool prof = dev->profiling;
-    HIP_TRY(hipMemsetAsync(fp.tile_count, 0, n_tiles * 4, s));
-    HIP_TRY(hipMemsetAsync(fp.counters, 0, CTR_COUNT * 4, s));
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CONSTANTS], s));
     launch_constants(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_VERTEX], s));
@@ -993,9 +991,11 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SETUP], s));
     launch_setup(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CLIP], s));
-    launch_clip(fp, s);
+    launch_clip(fp, dev->status_host[1], s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_TILE], s));
     launch_tile(fp, s);
+    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SHADE], s));
+    launch_shade(fp, s);
     if (prof) { HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_COUNT], s)); dev->stage_valid = true; }
     HIP_TRY(hipGetLastError());
     if (fence) {

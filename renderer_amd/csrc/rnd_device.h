@@ -40,13 +40,6 @@ __device__ __forceinline__ uint32_t depth24(float z)
     return d > 0xFFFFFFu ? 0xFFFFFFu : d;
 }
 
-/* Tables staged in LDS by the kernels that shade */
-struct ShadeTables {
-    float decode[256];
-    float thr[257];
-    uint8_t lut[SRGB_LUT_SIZE];
-};
-
 /* linear -> sRGB code: number of thresholds <= c; the bucket table gives a
  * lower bound that is at most two short */
 __device__ __forceinline__ uint32_t srgb_encode(const ShadeTables& tb, float c)

@@ -19,6 +19,7 @@ constexpr int CHUNK = 64;            /* primitives (or vertices) handled by one 
 constexpr int MAX_TILES_PER_PRIM = 16; /* primitives touching more tiles go to the pass-wide list */
 enum : uint32_t { CTR_LARGE = 0, CTR_CLIP = 1, CTR_CLIP_TRIS = 2, CTR_OVERFLOW = 3, CTR_COUNT = 4 };
 enum : uint32_t { OVF_LARGE = 1, OVF_CLIP = 2, OVF_CLIP_TRIS = 4 };
+constexpr int TILE_COUNT_STRIDE = 32; /* one tile counter per 128-byte line: atomics on neighbouring tiles do not share a line */
 constexpr int MAX_TILE_AXIS = 256;   /* tile coordinates are packed in 8 bits */
 constexpr int SUBPIXEL_BITS = 8;
 constexpr float GUARD_BAND = 2.0f;
@@ -30,6 +31,21 @@ enum : uint32_t {
 };
 
 constexpr uint32_t BBOX_CULLED = 0x000000FFu; /* tx0=255 > tx1=0: nothing to draw */
+
+/* float bits [2^-13, 1) >> 16: 13 octaves x 128 buckets */
+constexpr uint32_t SRGB_LUT_FIRST = 0x39000000u >> 16; /* 2^-13 */
+constexpr uint32_t SRGB_LUT_LAST = 0x3F800000u >> 16;  /* 1.0 */
+constexpr uint32_t SRGB_LUT_SIZE = SRGB_LUT_LAST - SRGB_LUT_FIRST;
+
+/* sRGB tables, staged in LDS by the kernels that shade: decode[k] = linear value of code k;
+ * thr[k] = linear value of code k-0.5 (thr[0] = -inf, thr[256] = +inf); lut[bucket] = number of
+ * thresholds not above the bucket's lower edge */
+struct __attribute__((aligned(16))) ShadeTables {
+    float decode[256];
+    float thr[257];
+    uint8_t lut[SRGB_LUT_SIZE];
+    uint8_t pad[12]; /* size is a multiple of 16 bytes */
+};
 
 /* Bits of TileEntry::slot_flags and PrimRec::draw_flags */
 constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   /* primitive slot (submission number) */
@@ -129,8 +145,9 @@ struct FrameParams {
     const Chunk* tchunks;
     const TexDesc* textures;
     SVtx* svtx;
+    float4* svary;           /* per vertex: transformed normal (shaders that light) */
     PrimRec* prim_rec;       /* per primitive slot */
-    uint32_t* tile_count;    /* per tile: entries appended this frame (may exceed tile_capacity) */
+    uint32_t* tile_count;    /* tile t at [t*TILE_COUNT_STRIDE]: entries appended this frame (may exceed tile_capacity) */
     TileEntry* tile_lists;   /* tile t owns entries [t*tile_capacity, (t+1)*tile_capacity) */
     LargeEntry* large_list;  /* primitives touching more than MAX_TILES_PER_PRIM tiles + tile-list overflow */
     uint32_t* clip_list;     /* slots that need the clipper */
@@ -140,9 +157,8 @@ struct FrameParams {
     uint32_t tile_capacity, large_capacity, clip_capacity, clip_tri_capacity;
     uint8_t* color;          /* resolved colour, width*height*4 */
     uint32_t* depth;         /* width*height*samples */
-    const float* srgb_decode; /* 256 floats */
-    const float* srgb_thr;    /* 257 floats */
-    const uint8_t* srgb_lut;  /* SRGB_LUT_SIZE bytes */
+    uint32_t* vis;           /* width*height*samples: owning primitive slot | fan index << 28, or 0xFFFFFFFF */
+    const struct ShadeTables* tables; /* sRGB decode / encode tables */
     uint32_t n_draws, n_vchunks, n_tchunks, n_textures;
     uint32_t width, height, samples;
     uint32_t color_srgb, color_bgra;
@@ -155,22 +171,20 @@ struct FrameParams {
     uint32_t clear_d24;
     uint32_t depth_less;     /* 1: LESS, 0: LESS_OR_EQUAL */
     uint32_t depth_test, depth_write;
+    uint32_t debug_flags;    /* timing experiments only: 1 skip shading, 2 skip rasterisation */
 };
 
-/* float bits [2^-13, 1) >> 16: 13 octaves x 128 buckets */
-constexpr uint32_t SRGB_LUT_FIRST = 0x39000000u >> 16; /* 2^-13 */
-constexpr uint32_t SRGB_LUT_LAST = 0x3F800000u >> 16;  /* 1.0 */
-constexpr uint32_t SRGB_LUT_SIZE = SRGB_LUT_LAST - SRGB_LUT_FIRST;
 
 /* launch wrappers (rnd_kernels.hip) */
 void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n_jobs, hipStream_t s);
 void launch_constants(const FrameParams& fp, hipStream_t s);
 void launch_vertex(const FrameParams& fp, hipStream_t s);
 void launch_setup(const FrameParams& fp, hipStream_t s);
-void launch_clip(const FrameParams& fp, hipStream_t s);
+void launch_clip(const FrameParams& fp, uint32_t expected, hipStream_t s);
 void launch_tile(const FrameParams& fp, hipStream_t s);
+void launch_shade(const FrameParams& fp, hipStream_t s);
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
-                const float* srgb_decode, const float* srgb_thr, const uint8_t* srgb_lut, hipStream_t s);
+                const struct ShadeTables* tables, hipStream_t s);
 
 } // namespace rnd
 #endif

@@ -10,8 +10,9 @@
  *                one atomic per wave and tile through ballot + popcount prefix)
  *   k_clip       the few primitives crossing near/far/guard band: clip, fan, bin
  *   k_tile       one workgroup per 32x32 tile: edge-function rasteriser into an LDS
- *                depth/owner word per sample, then one shading per covered pixel and
- *                coalesced colour/depth stores
+ *                depth/owner word per sample; stores depth and the owning primitive
+ *   k_shade      one thread per pixel: one shading per owning primitive, resolve,
+ *                sRGB encode, coalesced colour store
  *
  * Depth resolution is order independent: each fragment offers the 64-bit word
  * (D24 << 40 | inverted submission number << 8 | fan index) and the tile keeps the
@@ -51,8 +52,9 @@ struct PrimFetch {
 /* false: an index points outside the vertex buffer, the primitive is dropped */
 __device__ __forceinline__ bool fetch_prim(const FrameParams& fp, const DrawStatic& d, uint32_t tri, PrimFetch& pf)
 {
-    const uint32_t* ip = d.ib + (size_t)tri * 3;
-    pf.idx[0] = ip[0]; pf.idx[1] = ip[1]; pf.idx[2] = ip[2];
+    struct Idx3 { uint32_t a, b, c; };
+    const Idx3 ix = *reinterpret_cast<const Idx3*>(d.ib + (size_t)tri * 3); /* one 12-byte load */
+    pf.idx[0] = ix.a; pf.idx[1] = ix.b; pf.idx[2] = ix.c;
     if (pf.idx[0] >= d.vert_count || pf.idx[1] >= d.vert_count || pf.idx[2] >= d.vert_count) return false;
     const SVtx* sv = fp.svtx + d.svtx_base;
     pf.v[0] = sv[pf.idx[0]]; pf.v[1] = sv[pf.idx[1]]; pf.v[2] = sv[pf.idx[2]];
@@ -117,9 +119,13 @@ __global__ __launch_bounds__(256) void k_index_range(const IndexRangeJob* jobs, 
 
 /* ------------------------------------------------------------------ per-draw matrices */
 
+/* first kernel of a frame: clears this frame's tile counters and list counters, and builds
+ * the per-draw matrices from the uniform buffer as it is when the frame executes */
 __global__ __launch_bounds__(64) void k_constants(FrameParams fp)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < fp.tiles_x * fp.tiles_y) fp.tile_count[(size_t)i * TILE_COUNT_STRIDE] = 0;
+    if (i < CTR_COUNT) fp.counters[i] = 0;
     if (i >= fp.n_draws) return;
     const DrawStatic& d = fp.draws[i];
     DrawDerived out;
@@ -163,6 +169,20 @@ __global__ __launch_bounds__(256) void k_vertex(FrameParams fp)
         out.y = p.y; out.z = p.z; out.iw = p.iw;
     }
     fp.svtx[d.svtx_base + v] = out;
+    if (d.shader != 0) {
+        /* the rest of the vertex shader: v_normal (test_ktx.vert:30, push_constants.vert:30) */
+        float nrm[3] = {0.0f, 0.0f, 0.0f};
+        if (d.off_nrm >= 0) {
+            const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_nrm);
+            nrm[0] = p[0]; nrm[1] = p[1]; nrm[2] = p[2];
+        }
+        const float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
+        const float len = sqrtf(len2);
+        const float nn[3] = {nrm[0] / len, nrm[1] / len, nrm[2] / len};
+        float tn[3];
+        mat3_vec(fp.derived[c.draw].nrm_m, nn, tn);
+        fp.svary[d.svtx_base + v] = make_float4(tn[0], tn[1], tn[2], 0.0f);
+    }
 }
 
 /* ------------------------------------------------------------------ setup: cull, orient, bin (one pass) */
@@ -179,10 +199,26 @@ __device__ __forceinline__ void push_large(const FrameParams& fp, const TileEntr
     fp.large_list[pos] = le;
 }
 
-/* Appends every lane's entry to the lists of the tiles in its box, with wave-uniform
- * control flow.  Lanes of the wave that hit the same tile share one atomic: the leader
- * adds the population count and each lane takes base + its rank among those lanes
- * (ballot + popcount prefix).  A full tile list spills to the pass-wide list. */
+/* store an entry at a position of a tile's list, or spill it to the pass-wide list */
+__device__ __forceinline__ void put_entry(const FrameParams& fp, int tile, uint32_t pos, const TileEntry& e)
+{
+    if (pos < fp.tile_capacity) {
+        fp.tile_lists[(size_t)tile * fp.tile_capacity + pos] = e;
+    } else {
+        const int tx = tile % (int)fp.tiles_x, ty = tile / (int)fp.tiles_x;
+        push_large(fp, e, pack_bbox(tx, ty, tx, ty));
+    }
+}
+
+/* Appends every lane's entry to the lists of the tiles in its box.
+ *
+ * Tile 0 of every box (for small triangles the only one) is handled for the whole wave at
+ * once: lanes that hit the same tile are grouped with ballots (no memory traffic), then the
+ * leader of every group adds the group's size to its tile's counter -- all leaders in ONE
+ * vector atomic, so the wave pays one atomic round trip -- and each lane takes base + its
+ * rank inside the group (popcount of the lower lanes of the group).  Tiles 1..3 of a box
+ * issue their own atomics back to back before any result is used; boxes of more than 4
+ * tiles finish in a plain loop, more than MAX_TILES_PER_PRIM go to the pass-wide list. */
 __device__ __forceinline__ void bin_wave(const FrameParams& fp, bool valid, const TileEntry& e, uint32_t box)
 {
     const uint32_t lane = lane_id();
@@ -191,30 +227,42 @@ __device__ __forceinline__ void bin_wave(const FrameParams& fp, bool valid, cons
     int n = valid ? w * h : 0;
     const bool large = n > MAX_TILES_PER_PRIM;
     if (large) n = 0;
-    for (int k = 0;; ++k) {
-        const bool act = k < n;
-        if (__ballot(act) == 0ull) break;
-        int tile = -1;
-        if (act) {
-            const int ty = ty0 + k / w, tx = tx0 + k % w;
-            const int t = ty * (int)fp.tiles_x + tx;
-            if ((uint32_t)t % fp.shard_count == fp.shard_index) tile = t;
+    auto tile_of = [&](int k) -> int {
+        if (k >= n) return -1;
+        const int t = (ty0 + k / w) * (int)fp.tiles_x + tx0 + k % w;
+        return ((uint32_t)t % fp.shard_count == fp.shard_index) ? t : -1;
+    };
+    /* group the wave's first tiles */
+    const int t0 = tile_of(0);
+    uint64_t pending = __ballot(t0 >= 0);
+    int leader = -1;
+    uint32_t rank = 0, group = 0;
+    while (pending) {
+        const int l = __ffsll((unsigned long long)pending) - 1;
+        const int lt = __shfl(t0, l);
+        const uint64_t same = __ballot(t0 == lt);
+        if (t0 == lt) {
+            leader = l;
+            rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            group = (uint32_t)__popcll(same);
         }
-        uint64_t pending = __ballot(tile >= 0);
-        while (pending) {
-            const int leader = __ffsll((unsigned long long)pending) - 1;
-            const int lt = __shfl(tile, leader);
-            const uint64_t same = __ballot(tile == lt);
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&fp.tile_count[lt], (uint32_t)__popcll(same));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (tile == lt) {
-                const uint32_t pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                if (pos < fp.tile_capacity) fp.tile_lists[(size_t)lt * fp.tile_capacity + pos] = e;
-                else push_large(fp, e, pack_bbox(lt % (int)fp.tiles_x, lt / (int)fp.tiles_x, lt % (int)fp.tiles_x, lt / (int)fp.tiles_x));
-            }
-            pending &= ~same;
-        }
+        pending &= ~same;
+    }
+    /* issue every atomic before using any result */
+    uint32_t base0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    const int t1 = tile_of(1), t2 = tile_of(2), t3 = tile_of(3);
+    if ((int)lane == leader) base0 = atomicAdd(&fp.tile_count[(size_t)t0 * TILE_COUNT_STRIDE], group);
+    if (t1 >= 0) p1 = atomicAdd(&fp.tile_count[(size_t)t1 * TILE_COUNT_STRIDE], 1u);
+    if (t2 >= 0) p2 = atomicAdd(&fp.tile_count[(size_t)t2 * TILE_COUNT_STRIDE], 1u);
+    if (t3 >= 0) p3 = atomicAdd(&fp.tile_count[(size_t)t3 * TILE_COUNT_STRIDE], 1u);
+    base0 = (uint32_t)__shfl((int)base0, leader < 0 ? (int)lane : leader);
+    if (t0 >= 0) put_entry(fp, t0, base0 + rank, e);
+    if (t1 >= 0) put_entry(fp, t1, p1, e);
+    if (t2 >= 0) put_entry(fp, t2, p2, e);
+    if (t3 >= 0) put_entry(fp, t3, p3, e);
+    for (int k = 4; k < n; ++k) {
+        const int t = tile_of(k);
+        if (t >= 0) put_entry(fp, t, atomicAdd(&fp.tile_count[(size_t)t * TILE_COUNT_STRIDE], 1u), e);
     }
     if (large) push_large(fp, e, box);
 }
@@ -228,7 +276,7 @@ __device__ __forceinline__ void bin_one(const FrameParams& fp, const TileEntry& 
         for (int tx = tx0; tx <= tx1; ++tx) {
             const int t = ty * (int)fp.tiles_x + tx;
             if ((uint32_t)t % fp.shard_count != fp.shard_index) continue;
-            const uint32_t pos = atomicAdd(&fp.tile_count[t], 1u);
+            const uint32_t pos = atomicAdd(&fp.tile_count[(size_t)t * TILE_COUNT_STRIDE], 1u);
             if (pos < fp.tile_capacity) fp.tile_lists[(size_t)t * fp.tile_capacity + pos] = e;
             else push_large(fp, e, pack_bbox(tx, ty, tx, ty));
         }
@@ -249,7 +297,8 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp)
     uint32_t box = BBOX_CULLED;
     PrimFetch pf;
     if (tri < d.tri_count && fetch_prim(fp, d, tri, pf)) {
-        const int cls = classify_prim(pf);
+        const int cls = (fp.debug_flags & 4u) ? 0 : classify_prim(pf);
+        if (fp.debug_flags & 4u) { if (pf.oc_any == 0xFFFFu) fp.prim_rec[slot].v0 = 1; }
         if (cls == 2) {
             needs_clip = true;
         } else if (cls == 1) {
@@ -283,7 +332,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp)
             else flag_overflow(fp, OVF_CLIP);
         }
     }
-    bin_wave(fp, valid, e, box);
+    if (!(fp.debug_flags & 8u)) bin_wave(fp, valid, e, box);
 }
 
 /* ------------------------------------------------------------------ clipper: one lane per primitive that crosses
@@ -504,34 +553,43 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
 
 /* ---- fragment stage ---- */
 
-struct Varyings { float n[3]; float uv[2]; float col[3]; };
+struct Varyings { float n[3]; float uv[2]; };
 
-__device__ __forceinline__ void vs_varyings(const DrawStatic& d, const float* nrm_m, uint32_t v, Varyings& out)
+/* Vertex-shader outputs other than the position.  The normal was transformed by the vertex
+ * kernel (v_normal = inverse(transpose(mat3(model*transform))) * normalize(a_normal),
+ * test_ktx.vert:30); uv comes straight from the vertex buffer (dummy.vert.glsl:25 flips v). */
+__device__ __forceinline__ void load_varyings(const FrameParams& fp, const DrawStatic& d, uint32_t vtx, Varyings& out)
 {
-    const uint8_t* base = d.vb + (size_t)v * d.stride;
-    float nrm[3] = {0.0f, 0.0f, 0.0f}, uv[2] = {0.0f, 0.0f};
-    if (d.off_nrm >= 0) { const float* p = reinterpret_cast<const float*>(base + d.off_nrm); nrm[0] = p[0]; nrm[1] = p[1]; nrm[2] = p[2]; }
-    if (d.off_uv >= 0) { const float* p = reinterpret_cast<const float*>(base + d.off_uv); uv[0] = p[0]; uv[1] = p[1]; }
-    if (d.shader == 0) {
-        out.n[0] = nrm[0]; out.n[1] = nrm[1]; out.n[2] = nrm[2];
-        out.uv[0] = uv[0]; out.uv[1] = 1.0f - uv[1];
-        out.col[0] = out.col[1] = out.col[2] = 0.0f;
+    if (d.shader != 0) {
+        const float4 n = fp.svary[vtx];
+        out.n[0] = n.x; out.n[1] = n.y; out.n[2] = n.z;
     } else {
-        float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
-        float len = sqrtf(len2);
-        float nn[3] = {nrm[0] / len, nrm[1] / len, nrm[2] / len};
-        mat3_vec(nrm_m, nn, out.n);
-        out.uv[0] = uv[0]; out.uv[1] = uv[1];
-        out.col[0] = d.push[0]; out.col[1] = d.push[1]; out.col[2] = d.push[2];
+        out.n[0] = out.n[1] = out.n[2] = 0.0f; /* dummy.frag.glsl never reads v_normal */
     }
+    float u = 0.0f, v = 0.0f;
+    if (d.off_uv >= 0) {
+        const float2 t = *reinterpret_cast<const float2*>(d.vb + (size_t)(vtx - d.svtx_base) * d.stride + d.off_uv);
+        u = t.x; v = t.y;
+    }
+    out.uv[0] = u;
+    out.uv[1] = d.shader == 0 ? 1.0f - v : v;
 }
 
 /* perspective-correct weights over the parent's corners at a window position */
-__device__ __forceinline__ void parent_weights(const RTri& t, bool clipped, const float bary[3][3], int64_t px, int64_t py, float* lam)
+__device__ __forceinline__ void parent_weights(const RTri& t, bool small, bool clipped, const float bary[3][3], int64_t px, int64_t py, float* lam)
 {
-    float b0 = (float)edge64(t.x[1], t.y[1], t.x[2], t.y[2], px, py) * t.inv_area;
-    float b1 = (float)edge64(t.x[2], t.y[2], t.x[0], t.y[0], px, py) * t.inv_area;
-    float b2 = (float)edge64(t.x[0], t.y[0], t.x[1], t.y[1], px, py) * t.inv_area;
+    float b0, b1, b2;
+    if (small) {
+        /* extent below 32 pixels and the position at most a pixel outside the box: products fit 32 bits */
+        const int32_t qx = (int32_t)px, qy = (int32_t)py;
+        b0 = (float)((t.x[2] - t.x[1]) * (qy - t.y[1]) - (t.y[2] - t.y[1]) * (qx - t.x[1])) * t.inv_area;
+        b1 = (float)((t.x[0] - t.x[2]) * (qy - t.y[2]) - (t.y[0] - t.y[2]) * (qx - t.x[2])) * t.inv_area;
+        b2 = (float)((t.x[1] - t.x[0]) * (qy - t.y[0]) - (t.y[1] - t.y[0]) * (qx - t.x[0])) * t.inv_area;
+    } else {
+        b0 = (float)edge64(t.x[1], t.y[1], t.x[2], t.y[2], px, py) * t.inv_area;
+        b1 = (float)edge64(t.x[2], t.y[2], t.x[0], t.y[0], px, py) * t.inv_area;
+        b2 = (float)edge64(t.x[0], t.y[0], t.x[1], t.y[1], px, py) * t.inv_area;
+    }
     float p0 = b0 * t.iw[0], p1 = b1 * t.iw[1], p2 = b2 * t.iw[2];
     float den = (p0 + p1) + p2;
     float rden = 1.0f / den;
@@ -657,22 +715,26 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, uint32
         t.inv_area = 1.0f / (float)t.area2;
     }
     const DrawStatic& d = fp.draws[draw];
-    const DrawDerived& dd = fp.derived[draw];
     Varyings v0, v1, v2;
-    vs_varyings(d, dd.nrm_m, vtx[0] - d.svtx_base, v0);
-    vs_varyings(d, dd.nrm_m, vtx[1] - d.svtx_base, v1);
-    vs_varyings(d, dd.nrm_m, vtx[2] - d.svtx_base, v2);
+    load_varyings(fp, d, vtx[0], v0);
+    load_varyings(fp, d, vtx[1], v1);
+    load_varyings(fp, d, vtx[2], v2);
     const int64_t px = (int64_t)x * 256 + 128, py = (int64_t)y * 256 + 128;
+    const int ext = max(max(t.x[0], max(t.x[1], t.x[2])) - min(t.x[0], min(t.x[1], t.x[2])),
+                        max(t.y[0], max(t.y[1], t.y[2])) - min(t.y[0], min(t.y[1], t.y[2])));
+    /* a shaded pixel has a sample inside the triangle, so it and its quad neighbours are within
+     * two pixels of the box */
+    const bool small = ext < (1 << 13);
     float lam[3];
-    parent_weights(t, clipped, bary, px, py, lam);
+    parent_weights(t, small, clipped, bary, px, py, lam);
     float tex[3] = {1.0f, 1.0f, 1.0f};
     if (d.shader == 0 || d.shader == 1) {
         if (d.texture >= 0) {
             float u = interp(lam, v0.uv[0], v1.uv[0], v2.uv[0]), v = interp(lam, v0.uv[1], v1.uv[1], v2.uv[1]);
             /* derivatives inside the 2x2 pixel quad: the neighbour in x and the neighbour in y, same primitive */
             float lnx[3], lny[3];
-            parent_weights(t, clipped, bary, (int64_t)(x ^ 1) * 256 + 128, py, lnx);
-            parent_weights(t, clipped, bary, px, (int64_t)(y ^ 1) * 256 + 128, lny);
+            parent_weights(t, small, clipped, bary, (int64_t)(x ^ 1) * 256 + 128, py, lnx);
+            parent_weights(t, small, clipped, bary, px, (int64_t)(y ^ 1) * 256 + 128, lny);
             float unx = interp(lnx, v0.uv[0], v1.uv[0], v2.uv[0]), vnx = interp(lnx, v0.uv[1], v1.uv[1], v2.uv[1]);
             float uny = interp(lny, v0.uv[0], v1.uv[0], v2.uv[0]), vny = interp(lny, v0.uv[1], v1.uv[1], v2.uv[1]);
             float dudx = (x & 1) ? u - unx : unx - u, dvdx = (x & 1) ? v - vnx : vnx - v;
@@ -689,8 +751,9 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, uint32
     if (d.shader == 1) {
         rgba[0] = tex[0] * diff; rgba[1] = tex[1] * diff; rgba[2] = tex[2] * diff;
     } else {
-        float c0 = interp(lam, v0.col[0], v1.col[0], v2.col[0]), c1 = interp(lam, v0.col[1], v1.col[1], v2.col[1]),
-              c2 = interp(lam, v0.col[2], v1.col[2], v2.col[2]);
+        /* v_color = push colour at every corner, interpolated like any other varying */
+        float c0 = interp(lam, d.push[0], d.push[0], d.push[0]), c1 = interp(lam, d.push[1], d.push[1], d.push[1]),
+              c2 = interp(lam, d.push[2], d.push[2], d.push[2]);
         rgba[0] = c0 * diff; rgba[1] = c1 * diff; rgba[2] = c2 * diff;
     }
     rgba[3] = 1.0f;
@@ -705,11 +768,24 @@ __device__ __forceinline__ uint32_t pack_color(const FrameParams& fp, const Shad
     return fp.color_bgra ? (b | (g << 8) | (r << 16) | (a << 24)) : (r | (g << 8) | (b << 16) | (a << 24));
 }
 
+/* sRGB tables global -> LDS: one 16-byte load per thread */
+__device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables* src)
+{
+    static_assert(sizeof(ShadeTables) % 16 == 0, "tables are staged in 16-byte pieces");
+    const uint4* g = reinterpret_cast<const uint4*>(src);
+    uint4* l = reinterpret_cast<uint4*>(&tb);
+    for (uint32_t i = threadIdx.x; i < sizeof(ShadeTables) / 16; i += blockDim.x) l[i] = g[i];
+}
+
+constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* sample not covered by any fragment */
+
+/* One workgroup per 32x32 tile: rasterise the tile's triangles into one 64-bit word per sample
+ * held in LDS (depth, submission order, fan index; the minimum wins), then store the depth
+ * words and the winning primitive of every sample with full-row coalesced stores. */
 template <int S>
 __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
 {
     __shared__ unsigned long long keys[TILE_PIXELS * S];
-    __shared__ ShadeTables tb;
 
     const uint32_t tile = blockIdx.x * fp.shard_count + fp.shard_index;
     const int tx = (int)(tile % fp.tiles_x), ty = (int)(tile / fp.tiles_x);
@@ -722,14 +798,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
     for (uint32_t i = threadIdx.x; i < TILE_PIXELS * S; i += TILE_THREADS) keys[i] = clear_key;
-    for (uint32_t i = threadIdx.x; i < 256; i += TILE_THREADS) tb.decode[i] = fp.srgb_decode[i];
-    for (uint32_t i = threadIdx.x; i < 257; i += TILE_THREADS) tb.thr[i] = fp.srgb_thr[i];
-    for (uint32_t i = threadIdx.x; i < SRGB_LUT_SIZE; i += TILE_THREADS) tb.lut[i] = fp.srgb_lut[i];
     __syncthreads();
 
-    if (tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1) {
+    if (tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1 && !(fp.debug_flags & 2u)) {
         /* this tile's list: 16-byte entries, one per lane per batch */
-        const uint32_t count = min(fp.tile_count[tile], fp.tile_capacity);
+        const uint32_t count = min(fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE], fp.tile_capacity);
         const TileEntry* list = fp.tile_lists + (size_t)tile * fp.tile_capacity;
         for (uint32_t base = 0; base < count; base += TILE_THREADS) {
             const uint32_t i = base + threadIdx.x;
@@ -755,61 +828,83 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t ovf = fp.counters[CTR_OVERFLOW];
-        if (ovf) *fp.status_host = ovf; /* a list overflowed: the host reports it at the next wait */
+        if (ovf) fp.status_host[0] = ovf; /* a list overflowed: the host reports it at the next wait */
+        fp.status_host[1] = fp.counters[CTR_CLIP]; /* sizes the next frame's clip launch */
     }
     __syncthreads();
 
-    /* shade and store: consecutive lanes take consecutive pixels of a row, so a wave
-     * stores two full 128-byte row segments per step */
-    for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
+    /* consecutive lanes take consecutive samples of a row: a wave stores whole 128-byte segments */
+    for (uint32_t q = threadIdx.x; q < TILE_PIXELS * S; q += TILE_THREADS) {
+        const uint32_t p = q / S, s = q % S;
         const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
         if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
-        float acc[4];
-        float smp[S][4];
-        unsigned long long k[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) k[s] = keys[p * S + s];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            /* a sample still holding the clear word was never won by a fragment */
-            const bool covered = k[s] != clear_key;
-            /* one shading per (pixel, primitive): samples owned by the same fan triangle share it */
-            int reuse = -1;
-#pragma unroll
-            for (int s2 = 0; s2 < s; ++s2) {
-                if (reuse < 0 && ((k[s2] ^ k[s]) & 0xFFFFFFFFFFull) == 0ull && k[s2] != clear_key) reuse = s2;
-            }
-            if (!covered) {
-                smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
-            } else if (reuse >= 0) {
-                smp[s][0] = smp[reuse][0]; smp[s][1] = smp[reuse][1]; smp[s][2] = smp[reuse][2]; smp[s][3] = smp[reuse][3];
-            } else {
-                const uint32_t low = (uint32_t)(k[s] >> 8);
-                const uint32_t slot = fp.depth_less ? low : ~low;
-                shade_pixel(fp, tb, slot, (uint32_t)(k[s] & 255ull), x, y, smp[s]);
-            }
-            const uint32_t d24 = fp.depth_test ? (uint32_t)(k[s] >> 40) : fp.clear_d24;
-            fp.depth[((size_t)y * fp.width + (size_t)x) * S + s] = d24;
+        const unsigned long long k = keys[q];
+        const size_t gi = ((size_t)y * fp.width + (size_t)x) * S + s;
+        fp.depth[gi] = fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24;
+        uint32_t vis = VIS_NONE;
+        if (k != clear_key) {
+            const uint32_t low = (uint32_t)(k >> 8);
+            vis = (fp.depth_less ? low : ~low) | ((uint32_t)(k & 7ull) << ENTRY_SUB_SHIFT);
         }
-        if constexpr (S == 1) {
-            acc[0] = smp[0][0]; acc[1] = smp[0][1]; acc[2] = smp[0][2]; acc[3] = smp[0][3];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = ((smp[0][c] + smp[1][c]) + (smp[2][c] + smp[3][c])) * 0.25f;
-        }
-        reinterpret_cast<uint32_t*>(fp.color)[(size_t)y * fp.width + (size_t)x] = pack_color(fp, tb, acc);
+        fp.vis[gi] = vis;
     }
+}
+
+/* One thread per pixel: shade the primitive that owns each sample (once per distinct fan
+ * triangle), resolve, encode, store.  Workgroup = 32x8 pixels, lanes along x. */
+template <int S>
+__global__ __launch_bounds__(256) void k_shade(FrameParams fp)
+{
+    __shared__ ShadeTables tb;
+    stage_tables(tb, fp.tables);
+    __syncthreads();
+    const int x = (int)(blockIdx.x * 32u + (threadIdx.x & 31u)), y = (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
+    if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) return;
+    if (fp.shard_count > 1) {
+        const uint32_t tile = (uint32_t)(y >> TILE_SHIFT) * fp.tiles_x + (uint32_t)(x >> TILE_SHIFT);
+        if (tile % fp.shard_count != fp.shard_index) return;
+    }
+    const size_t pi = (size_t)y * fp.width + (size_t)x;
+    uint32_t vis[S];
+    if constexpr (S == 4) {
+        const uint4 v4 = reinterpret_cast<const uint4*>(fp.vis)[pi];
+        vis[0] = v4.x; vis[1] = v4.y; vis[2] = v4.z; vis[3] = v4.w;
+    } else {
+        vis[0] = fp.vis[pi];
+    }
+    float smp[S][4];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int reuse = -1;
+#pragma unroll
+        for (int s2 = 0; s2 < s; ++s2) if (reuse < 0 && vis[s2] == vis[s]) reuse = s2;
+        if (reuse >= 0) {
+            smp[s][0] = smp[reuse][0]; smp[s][1] = smp[reuse][1]; smp[s][2] = smp[reuse][2]; smp[s][3] = smp[reuse][3];
+        } else if (vis[s] == VIS_NONE) {
+            smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
+        } else if (fp.debug_flags & 1u) {
+            smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.5f;
+        } else {
+            shade_pixel(fp, tb, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, x, y, smp[s]);
+        }
+    }
+    float acc[4];
+    if constexpr (S == 1) {
+        acc[0] = smp[0][0]; acc[1] = smp[0][1]; acc[2] = smp[0][2]; acc[3] = smp[0][3];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = ((smp[0][c] + smp[1][c]) + (smp[2][c] + smp[3][c])) * 0.25f;
+    }
+    reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, acc);
 }
 
 /* ------------------------------------------------------------------ mip generation (blit LINEAR, tools.cpp:670-707) */
 
 __global__ __launch_bounds__(256) void k_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh,
-                                             int srgb, const float* g_decode, const float* g_thr, const uint8_t* g_lut)
+                                             int srgb, const ShadeTables* tables)
 {
     __shared__ ShadeTables tb;
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) tb.decode[i] = g_decode[i];
-    for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x) tb.thr[i] = g_thr[i];
-    for (uint32_t i = threadIdx.x; i < SRGB_LUT_SIZE; i += blockDim.x) tb.lut[i] = g_lut[i];
+    stage_tables(tb, tables);
     __syncthreads();
     const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
     const size_t total = (size_t)dw * dh;
@@ -852,8 +947,10 @@ void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n
 
 void launch_constants(const FrameParams& fp, hipStream_t s)
 {
-    if (!fp.n_draws) return;
-    hipLaunchKernelGGL(k_constants, dim3((fp.n_draws + 63) / 64), dim3(64), 0, s, fp);
+    uint32_t n = fp.tiles_x * fp.tiles_y;
+    if (fp.n_draws > n) n = fp.n_draws;
+    if (n < CTR_COUNT) n = CTR_COUNT;
+    hipLaunchKernelGGL(k_constants, dim3((n + 63) / 64), dim3(64), 0, s, fp);
 }
 
 void launch_vertex(const FrameParams& fp, hipStream_t s)
@@ -868,10 +965,14 @@ void launch_setup(const FrameParams& fp, hipStream_t s)
     hipLaunchKernelGGL(k_setup, dim3((fp.n_tchunks + 3) / 4), dim3(256), 0, s, fp);
 }
 
-void launch_clip(const FrameParams& fp, hipStream_t s)
+void launch_clip(const FrameParams& fp, uint32_t expected, hipStream_t s)
 {
     if (!fp.n_tchunks) return;
-    hipLaunchKernelGGL(k_clip, dim3(256), dim3(64), 0, s, fp);
+    /* grid-stride kernel: any grid is correct; size it for the count the previous frame saw */
+    uint32_t blocks = (expected + expected / 4 + 63) / 64;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(64), 0, s, fp);
 }
 
 void launch_tile(const FrameParams& fp, hipStream_t s)
@@ -883,13 +984,20 @@ void launch_tile(const FrameParams& fp, hipStream_t s)
     else hipLaunchKernelGGL(k_tile<1>, dim3(mine), dim3(TILE_THREADS), 0, s, fp);
 }
 
+void launch_shade(const FrameParams& fp, hipStream_t s)
+{
+    const dim3 grid((fp.width + 31) / 32, (fp.height + 7) / 8);
+    if (fp.samples == 4) hipLaunchKernelGGL(k_shade<4>, grid, dim3(256), 0, s, fp);
+    else hipLaunchKernelGGL(k_shade<1>, grid, dim3(256), 0, s, fp);
+}
+
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
-                const float* srgb_decode, const float* srgb_thr, const uint8_t* srgb_lut, hipStream_t s)
+                const ShadeTables* tables, hipStream_t s)
 {
     size_t total = (size_t)dw * dh;
     uint32_t blocks = (uint32_t)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_mip, dim3(blocks), dim3(256), 0, s, src, sw, sh, dst, dw, dh, srgb, srgb_decode, srgb_thr, srgb_lut);
+    hipLaunchKernelGGL(k_mip, dim3(blocks), dim3(256), 0, s, src, sw, sh, dst, dw, dh, srgb, tables);
 }
 
 } // namespace rnd
