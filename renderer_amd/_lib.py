@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librenderer_amd.so")
+# RENDERER_AMD_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("RENDERER_AMD_LIB") or os.path.join(_HERE, "librenderer_amd.so")
 
 # every symbol include/renderer_amd.h declares
 SYMBOLS = [

@@ -160,7 +160,7 @@ struct rnd_cmd_t {
     DeviceArray<Chunk> d_vchunks, d_tchunks;
     DeviceArray<TexDesc> d_textures;
     DeviceArray<SVtx> d_svtx;
-    DeviceArray<float4> d_svary;
+    DeviceArray<SVary> d_svary;
     DeviceArray<PrimRec> d_prim_rec;
     DeviceArray<TileEntry> d_tile_lists;
     DeviceArray<LargeEntry> d_large_list;
@@ -952,6 +952,13 @@ int rnd_cmd_end(rnd_cmd cmd)
     } else {
         fp.clamp_x0 = 0; fp.clamp_y0 = 0; fp.clamp_x1 = -1; fp.clamp_y1 = -1;
     }
+    fp.pass_shader = n ? ds[0].shader : -1;
+    fp.pass_texture = n ? ds[0].texture : -1;
+    for (size_t i = 1; i < n; ++i) {
+        if (ds[i].shader != fp.pass_shader) fp.pass_shader = -1;
+        if (ds[i].texture != fp.pass_texture) fp.pass_texture = -2;
+    }
+    if (fp.pass_texture >= 0) fp.pass_tex = td[(size_t)fp.pass_texture];
     memcpy(fp.clear_color, cmd->clear_color, 16);
     fp.clear_d24 = host_depth24(cmd->clear_depth);
     fp.depth_test = (uint32_t)depth_test;

@@ -95,6 +95,13 @@ struct SVtx {
     float iw;    /* 1/w */
 };
 
+/* Vertex-shader outputs besides the position: 32 bytes, two dwordx4 loads per corner in shading */
+struct __attribute__((aligned(32))) SVary {
+    float nx, ny, nz; /* v_normal (zero for the dummy shader, which does not light) */
+    float u, v;       /* a_uv as stored */
+    float pad[3];
+};
+
 /* Per-draw record, immutable after recording */
 struct DrawStatic {
     const uint8_t* vb;   /* vertex 0 of the draw (binding offset and vertex_offset applied) */
@@ -145,7 +152,7 @@ struct FrameParams {
     const Chunk* tchunks;
     const TexDesc* textures;
     SVtx* svtx;
-    float4* svary;           /* per vertex: transformed normal (shaders that light) */
+    struct SVary* svary;     /* per vertex: the vertex shader's other outputs */
     PrimRec* prim_rec;       /* per primitive slot */
     uint32_t* tile_count;    /* tile t at [t*TILE_COUNT_STRIDE]: entries appended this frame (may exceed tile_capacity) */
     TileEntry* tile_lists;   /* tile t owns entries [t*tile_capacity, (t+1)*tile_capacity) */
@@ -171,6 +178,9 @@ struct FrameParams {
     uint32_t clear_d24;
     uint32_t depth_less;     /* 1: LESS, 0: LESS_OR_EQUAL */
     uint32_t depth_test, depth_write;
+    int32_t pass_shader;     /* shader of every draw of the pass, or -1 when they differ */
+    int32_t pass_texture;    /* texture index of every draw (-1: none bound), or -2 when they differ */
+    TexDesc pass_tex;        /* textures[pass_texture] by value */
     uint32_t debug_flags;    /* timing experiments only: 1 skip shading, 2 skip rasterisation */
 };
 

@@ -169,8 +169,14 @@ __global__ __launch_bounds__(256) void k_vertex(FrameParams fp)
         out.y = p.y; out.z = p.z; out.iw = p.iw;
     }
     fp.svtx[d.svtx_base + v] = out;
+    /* the rest of the vertex shader: v_normal (test_ktx.vert:30, push_constants.vert:30) and v_uv */
+    SVary vo;
+    vo.nx = vo.ny = vo.nz = 0.0f; vo.u = vo.v = 0.0f; vo.pad[0] = vo.pad[1] = vo.pad[2] = 0.0f;
+    if (d.off_uv >= 0) {
+        const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_uv);
+        vo.u = p[0]; vo.v = p[1];
+    }
     if (d.shader != 0) {
-        /* the rest of the vertex shader: v_normal (test_ktx.vert:30, push_constants.vert:30) */
         float nrm[3] = {0.0f, 0.0f, 0.0f};
         if (d.off_nrm >= 0) {
             const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_nrm);
@@ -181,8 +187,9 @@ __global__ __launch_bounds__(256) void k_vertex(FrameParams fp)
         const float nn[3] = {nrm[0] / len, nrm[1] / len, nrm[2] / len};
         float tn[3];
         mat3_vec(fp.derived[c.draw].nrm_m, nn, tn);
-        fp.svary[d.svtx_base + v] = make_float4(tn[0], tn[1], tn[2], 0.0f);
+        vo.nx = tn[0]; vo.ny = tn[1]; vo.nz = tn[2];
     }
+    fp.svary[d.svtx_base + v] = vo;
 }
 
 /* ------------------------------------------------------------------ setup: cull, orient, bin (one pass) */
@@ -555,24 +562,15 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
 
 struct Varyings { float n[3]; float uv[2]; };
 
-/* Vertex-shader outputs other than the position.  The normal was transformed by the vertex
- * kernel (v_normal = inverse(transpose(mat3(model*transform))) * normalize(a_normal),
- * test_ktx.vert:30); uv comes straight from the vertex buffer (dummy.vert.glsl:25 flips v). */
-__device__ __forceinline__ void load_varyings(const FrameParams& fp, const DrawStatic& d, uint32_t vtx, Varyings& out)
+/* Vertex-shader outputs other than the position, as the vertex kernel left them */
+__device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vtx, int shader, Varyings& out)
 {
-    if (d.shader != 0) {
-        const float4 n = fp.svary[vtx];
-        out.n[0] = n.x; out.n[1] = n.y; out.n[2] = n.z;
-    } else {
-        out.n[0] = out.n[1] = out.n[2] = 0.0f; /* dummy.frag.glsl never reads v_normal */
-    }
-    float u = 0.0f, v = 0.0f;
-    if (d.off_uv >= 0) {
-        const float2 t = *reinterpret_cast<const float2*>(d.vb + (size_t)(vtx - d.svtx_base) * d.stride + d.off_uv);
-        u = t.x; v = t.y;
-    }
-    out.uv[0] = u;
-    out.uv[1] = d.shader == 0 ? 1.0f - v : v;
+    const float4* rec = reinterpret_cast<const float4*>(&fp.svary[vtx]);
+    const float4 a = rec[0];
+    const float v = reinterpret_cast<const float*>(rec)[4];
+    out.n[0] = a.x; out.n[1] = a.y; out.n[2] = a.z;
+    out.uv[0] = a.w;
+    out.uv[1] = shader == 0 ? 1.0f - v : v; /* dummy.vert.glsl:25 flips v */
 }
 
 /* perspective-correct weights over the parent's corners at a window position */
@@ -714,11 +712,13 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, uint32
         t.area2 = edge64(t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2]);
         t.inv_area = 1.0f / (float)t.area2;
     }
-    const DrawStatic& d = fp.draws[draw];
+    /* shader and texture come from the kernel arguments when every draw of the pass agrees,
+     * which saves two dependent loads per pixel; otherwise from the draw's record */
+    const int shader = fp.pass_shader >= 0 ? fp.pass_shader : fp.draws[draw].shader;
     Varyings v0, v1, v2;
-    load_varyings(fp, d, vtx[0], v0);
-    load_varyings(fp, d, vtx[1], v1);
-    load_varyings(fp, d, vtx[2], v2);
+    load_varyings(fp, vtx[0], shader, v0);
+    load_varyings(fp, vtx[1], shader, v1);
+    load_varyings(fp, vtx[2], shader, v2);
     const int64_t px = (int64_t)x * 256 + 128, py = (int64_t)y * 256 + 128;
     const int ext = max(max(t.x[0], max(t.x[1], t.x[2])) - min(t.x[0], min(t.x[1], t.x[2])),
                         max(t.y[0], max(t.y[1], t.y[2])) - min(t.y[0], min(t.y[1], t.y[2])));
@@ -728,8 +728,9 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, uint32
     float lam[3];
     parent_weights(t, small, clipped, bary, px, py, lam);
     float tex[3] = {1.0f, 1.0f, 1.0f};
-    if (d.shader == 0 || d.shader == 1) {
-        if (d.texture >= 0) {
+    if (shader == 0 || shader == 1) {
+        const int texture = fp.pass_texture != -2 ? fp.pass_texture : fp.draws[draw].texture;
+        if (texture >= 0) {
             float u = interp(lam, v0.uv[0], v1.uv[0], v2.uv[0]), v = interp(lam, v0.uv[1], v1.uv[1], v2.uv[1]);
             /* derivatives inside the 2x2 pixel quad: the neighbour in x and the neighbour in y, same primitive */
             float lnx[3], lny[3];
@@ -739,21 +740,23 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, uint32
             float uny = interp(lny, v0.uv[0], v1.uv[0], v2.uv[0]), vny = interp(lny, v0.uv[1], v1.uv[1], v2.uv[1]);
             float dudx = (x & 1) ? u - unx : unx - u, dvdx = (x & 1) ? v - vnx : vnx - v;
             float dudy = (y & 1) ? u - uny : uny - u, dvdy = (y & 1) ? v - vny : vny - v;
-            sample_texture(tb, fp.textures[d.texture], u, v, dudx, dvdx, dudy, dvdy, tex);
+            if (fp.pass_texture >= 0) sample_texture(tb, fp.pass_tex, u, v, dudx, dvdx, dudy, dvdy, tex);
+            else sample_texture(tb, fp.textures[texture], u, v, dudx, dvdx, dudy, dvdy, tex);
         } else {
             tex[0] = tex[1] = tex[2] = 0.0f;
         }
     }
-    if (d.shader == 0) { rgba[0] = tex[0]; rgba[1] = tex[1]; rgba[2] = tex[2]; rgba[3] = 1.0f; return; }
+    if (shader == 0) { rgba[0] = tex[0]; rgba[1] = tex[1]; rgba[2] = tex[2]; rgba[3] = 1.0f; return; }
     float n[3] = {interp(lam, v0.n[0], v1.n[0], v2.n[0]), interp(lam, v0.n[1], v1.n[1], v2.n[1]), interp(lam, v0.n[2], v1.n[2], v2.n[2])};
     const float lx = 0.0f, ly = 0.70710678118654752f, lz = -0.70710678118654752f;
     float diff = fmaxf(fma32(n[2], lz, fma32(n[1], ly, n[0] * lx)), 0.0f);
-    if (d.shader == 1) {
+    if (shader == 1) {
         rgba[0] = tex[0] * diff; rgba[1] = tex[1] * diff; rgba[2] = tex[2] * diff;
     } else {
         /* v_color = push colour at every corner, interpolated like any other varying */
-        float c0 = interp(lam, d.push[0], d.push[0], d.push[0]), c1 = interp(lam, d.push[1], d.push[1], d.push[1]),
-              c2 = interp(lam, d.push[2], d.push[2], d.push[2]);
+        const float* col = fp.draws[draw].push;
+        float c0 = interp(lam, col[0], col[0], col[0]), c1 = interp(lam, col[1], col[1], col[1]),
+              c2 = interp(lam, col[2], col[2], col[2]);
         rgba[0] = c0 * diff; rgba[1] = c1 * diff; rgba[2] = c2 * diff;
     }
     rgba[3] = 1.0f;
