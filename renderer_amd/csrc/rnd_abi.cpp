@@ -904,7 +904,8 @@ int rnd_cmd_end(rnd_cmd cmd)
     HIP_TRY(cmd->d_svary.resize((size_t)svtx_total));
     HIP_TRY(cmd->d_prim_rec.resize(slots));
     HIP_TRY(cmd->d_tile_count.resize(n_tiles * TILE_COUNT_STRIDE));
-    HIP_TRY(cmd->d_tile_lists.resize(n_tiles * tile_cap));
+    const size_t tile_stride = tile_cap + 16;
+    HIP_TRY(cmd->d_tile_lists.resize(n_tiles * tile_stride));
     HIP_TRY(cmd->d_large_list.resize(large_cap));
     HIP_TRY(cmd->d_clip_list.resize(clip_cap));
     HIP_TRY(cmd->d_clip_tris.resize(clip_tri_cap));
@@ -918,7 +919,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     fp.tile_count = cmd->d_tile_count.ptr; fp.tile_lists = cmd->d_tile_lists.ptr;
     fp.large_list = cmd->d_large_list.ptr; fp.clip_list = cmd->d_clip_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
     fp.counters = cmd->d_counters.ptr;
-    fp.tile_capacity = (uint32_t)tile_cap; fp.large_capacity = (uint32_t)large_cap;
+    fp.tile_capacity = (uint32_t)tile_cap; fp.tile_stride = (uint32_t)tile_stride; fp.large_capacity = (uint32_t)large_cap;
     fp.clip_capacity = (uint32_t)clip_cap; fp.clip_tri_capacity = (uint32_t)clip_tri_cap;
     {
         void* dp = nullptr;

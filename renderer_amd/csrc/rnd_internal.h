@@ -155,13 +155,15 @@ struct FrameParams {
     struct SVary* svary;     /* per vertex: the vertex shader's other outputs */
     PrimRec* prim_rec;       /* per primitive slot */
     uint32_t* tile_count;    /* tile t at [t*TILE_COUNT_STRIDE]: entries appended this frame (may exceed tile_capacity) */
-    TileEntry* tile_lists;   /* tile t owns entries [t*tile_capacity, (t+1)*tile_capacity) */
+    TileEntry* tile_lists;   /* tile t owns entries [t*tile_stride, t*tile_stride + tile_capacity) */
     LargeEntry* large_list;  /* primitives touching more than MAX_TILES_PER_PRIM tiles + tile-list overflow */
     uint32_t* clip_list;     /* slots that need the clipper */
     ClipTri* clip_tris;
     uint32_t* counters;      /* [0] large_list entries, [1] clip_list entries, [2] clip_tris used, [3] overflow flags */
     uint32_t* status_host;   /* pinned host word: overflow flags of the last frame that had any */
     uint32_t tile_capacity, large_capacity, clip_capacity, clip_tri_capacity;
+    uint32_t tile_stride;    /* capacity + 16 entries: lists do not all start on the same power-of-two boundary
+                                (equal low address bits would pile every tile onto the same memory channels) */
     uint8_t* color;          /* resolved colour, width*height*4 */
     uint32_t* depth;         /* width*height*samples */
     uint32_t* vis;           /* width*height*samples: owning primitive slot | fan index << 28, or 0xFFFFFFFF */

@@ -210,7 +210,7 @@ __device__ __forceinline__ void push_large(const FrameParams& fp, const TileEntr
 __device__ __forceinline__ void put_entry(const FrameParams& fp, int tile, uint32_t pos, const TileEntry& e)
 {
     if (pos < fp.tile_capacity) {
-        fp.tile_lists[(size_t)tile * fp.tile_capacity + pos] = e;
+        fp.tile_lists[(size_t)tile * fp.tile_stride + pos] = e;
     } else {
         const int tx = tile % (int)fp.tiles_x, ty = tile / (int)fp.tiles_x;
         push_large(fp, e, pack_bbox(tx, ty, tx, ty));
@@ -284,7 +284,7 @@ __device__ __forceinline__ void bin_one(const FrameParams& fp, const TileEntry& 
             const int t = ty * (int)fp.tiles_x + tx;
             if ((uint32_t)t % fp.shard_count != fp.shard_index) continue;
             const uint32_t pos = atomicAdd(&fp.tile_count[(size_t)t * TILE_COUNT_STRIDE], 1u);
-            if (pos < fp.tile_capacity) fp.tile_lists[(size_t)t * fp.tile_capacity + pos] = e;
+            if (pos < fp.tile_capacity) fp.tile_lists[(size_t)t * fp.tile_stride + pos] = e;
             else push_large(fp, e, pack_bbox(tx, ty, tx, ty));
         }
     }
@@ -409,6 +409,9 @@ struct RasterTri {
 
 /* Per-sample test + depth + LDS min for one pixel.  I is int32_t when every edge product
  * fits 32 bits (extent below 64 pixels), else int64_t; both give the same integers. */
+__device__ __forceinline__ int32_t edge_mul(int32_t a, int32_t b) { return __mul24(a, b); } /* operands below 2^15: full-rate multiply */
+__device__ __forceinline__ int64_t edge_mul(int64_t a, int64_t b) { return a * b; }
+
 template <typename I, int S>
 struct EdgeSetup {
     I ax0, ay0, ax1, ay1, ax2, ay2;
@@ -429,12 +432,22 @@ struct EdgeSetup {
         bias0 = owns_edge(t.x[1], t.y[1], t.x[2], t.y[2]) ? 0 : 1;
         bias1 = owns_edge(t.x[2], t.y[2], t.x[0], t.y[0]) ? 0 : 1;
         bias2 = owns_edge(t.x[0], t.y[0], t.x[1], t.y[1]) ? 0 : 1;
-        const int64_t area2 = edge64(t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2]);
+        const I area2 = edge_mul(dx2, (I)t.y[2] - (I)t.y[0]) - edge_mul(dy2, (I)t.x[2] - (I)t.x[0]);
         inv_area = 1.0f / (float)area2;
         z0 = t.z[0]; dz1 = t.z[1] - t.z[0]; dz2 = t.z[2] - t.z[0];
         const uint32_t ord = fp.depth_less ? t.slot : ~t.slot;
         payload = ((unsigned long long)ord << 8) | (unsigned long long)t.payload_lo;
         depth_test = fp.depth_test;
+    }
+
+    /* depth of a covered sample from its edge values, then the LDS minimum.  No read first:
+     * the atomic needs no result, so the lane does not wait for the LDS */
+    __device__ __forceinline__ void emit(const TileCtx& tc, uint32_t word_index, I e1, I e2) const
+    {
+        const float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
+        const float z = fma32(b2, dz2, fma32(b1, dz1, z0));
+        const uint32_t d24 = depth_test ? depth24(z) : 0u;
+        atomicMin(&tc.keys[word_index], ((unsigned long long)d24 << 40) | payload);
     }
 
     __device__ __forceinline__ void pixel(const TileCtx& tc, int x, int y) const
@@ -444,16 +457,11 @@ struct EdgeSetup {
         for (int s = 0; s < S; ++s) {
             const I px = (I)(x * 256 + (S == 1 ? 128 : c_sample_x4[s]));
             const I py = (I)(y * 256 + (S == 1 ? 128 : c_sample_y4[s]));
-            const I e0 = dx0 * (py - ay0) - dy0 * (px - ax0);
-            const I e1 = dx1 * (py - ay1) - dy1 * (px - ax1);
-            const I e2 = dx2 * (py - ay2) - dy2 * (px - ax2);
+            const I e0 = edge_mul(dx0, py - ay0) - edge_mul(dy0, px - ax0);
+            const I e1 = edge_mul(dx1, py - ay1) - edge_mul(dy1, px - ax1);
+            const I e2 = edge_mul(dx2, py - ay2) - edge_mul(dy2, px - ax2);
             if (((e0 - bias0) | (e1 - bias1) | (e2 - bias2)) < 0) continue;
-            const float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
-            const float z = fma32(b2, dz2, fma32(b1, dz1, z0));
-            const uint32_t d24 = depth_test ? depth24(z) : 0u;
-            const unsigned long long key = ((unsigned long long)d24 << 40) | payload;
-            unsigned long long* word = &tc.keys[pix * S + s];
-            if (key < *word) atomicMin(word, key); /* early depth test: read, then the LDS atomic */
+            emit(tc, pix * S + s, e1, e2);
         }
     }
 };
@@ -476,17 +484,34 @@ __device__ __forceinline__ bool tri_is_small(const RasterTri& t)
     return ext < (1 << 14);
 }
 
-/* one lane walks its own triangle's box */
+/* one lane walks its own (small) triangle's box.  With one sample per pixel the three edge
+ * values are stepped incrementally: one add per edge per pixel, multiplies only at the start. */
 template <int S>
 __device__ __forceinline__ void raster_lane(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int x1, int y1)
 {
-    if (tri_is_small(t)) {
-        EdgeSetup<int32_t, S> es;
-        es.init(fp, t);
-        for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) es.pixel(tc, x, y);
+    EdgeSetup<int32_t, S> es;
+    es.init(fp, t);
+    if constexpr (S == 1) {
+        const int32_t px = x0 * 256 + 128, py = y0 * 256 + 128;
+        /* the ownership bias is folded into the start values and taken out again for the depth */
+        int32_t r0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0) - es.bias0;
+        int32_t r1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1) - es.bias1;
+        int32_t r2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2) - es.bias2;
+        const int32_t sx0 = -(es.dy0 << 8), sx1 = -(es.dy1 << 8), sx2 = -(es.dy2 << 8); /* one pixel right */
+        const int32_t sy0 = es.dx0 << 8, sy1 = es.dx1 << 8, sy2 = es.dx2 << 8;          /* one pixel down */
+        uint32_t row = (uint32_t)((y0 - tc.py0) * TILE_W + (x0 - tc.px0));
+        for (int y = y0; y <= y1; ++y) {
+            int32_t e0 = r0, e1 = r1, e2 = r2;
+            uint32_t pix = row;
+            for (int x = x0; x <= x1; ++x) {
+                if ((e0 | e1 | e2) >= 0) es.emit(tc, pix, e1 + es.bias1, e2 + es.bias2);
+                e0 += sx0; e1 += sx1; e2 += sx2;
+                ++pix;
+            }
+            r0 += sy0; r1 += sy1; r2 += sy2;
+            row += TILE_W;
+        }
     } else {
-        EdgeSetup<int64_t, S> es;
-        es.init(fp, t);
         for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) es.pixel(tc, x, y);
     }
 }
@@ -542,8 +567,10 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
     int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
     const bool hit = have && tri_box_in_tile(fp, tc, t, x0, y0, x1, y1);
     const int area = hit ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
-    if (hit && area <= LANE_RASTER_MAX_PIXELS) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
-    uint64_t big = __ballot(hit && area > LANE_RASTER_MAX_PIXELS);
+    const bool by_lane = hit && area <= LANE_RASTER_MAX_PIXELS && tri_is_small(t);
+    if (fp.debug_flags & 128u) { if (hit && t.z[0] == 123.0f) tc.keys[0] = 0; return; }
+    if (by_lane) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
+    uint64_t big = __ballot(hit && !by_lane);
     while (big) {
         const int src = __ffsll((unsigned long long)big) - 1;
         big &= big - 1;
@@ -771,6 +798,34 @@ __device__ __forceinline__ uint32_t pack_color(const FrameParams& fp, const Shad
     return fp.color_bgra ? (b | (g << 8) | (r << 16) | (a << 24)) : (r | (g << 8) | (b << 16) | (a << 24));
 }
 
+/* Streams n entries through the rasteriser in batches of one entry per lane, as a three-stage
+ * software pipeline: while batch b is rasterised, the vertices of batch b+1 and the entries of
+ * batch b+2 are already in flight, so a batch does not wait for two dependent memory round trips. */
+template <int S, typename Fetch>
+__device__ __forceinline__ void raster_stream(const FrameParams& fp, const TileCtx& tc, uint32_t n, Fetch fetch)
+{
+    if (n == 0) return;
+    const uint32_t tid = threadIdx.x;
+    TileEntry e_in = {0, 0, 0, 0}, e_mid = {0, 0, 0, 0};
+    RasterTri t_cur, t_next;
+    bool h_cur = false, h_next = false, h_mid = false, h_in = false;
+    {
+        TileEntry e0;
+        h_cur = tid < n && fetch(tid, e0);
+        if (h_cur) h_cur = load_raster_tri(fp, e0, t_cur);
+        h_mid = tid + TILE_THREADS < n && fetch(tid + TILE_THREADS, e_mid);
+    }
+    for (uint32_t base = 0; base < n; base += TILE_THREADS) {
+        const uint32_t i2 = base + 2u * TILE_THREADS + tid;
+        h_in = i2 < n && fetch(i2, e_in);
+        h_next = h_mid;
+        if (h_next) h_next = load_raster_tri(fp, e_mid, t_next);
+        raster_batch<S>(fp, tc, h_cur, t_cur);
+        t_cur = t_next; h_cur = h_next;
+        e_mid = e_in; h_mid = h_in;
+    }
+}
+
 /* sRGB tables global -> LDS: one 16-byte load per thread */
 __device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables* src)
 {
@@ -805,29 +860,19 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
 
     if (tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1 && !(fp.debug_flags & 2u)) {
         /* this tile's list: 16-byte entries, one per lane per batch */
-        const uint32_t count = min(fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE], fp.tile_capacity);
-        const TileEntry* list = fp.tile_lists + (size_t)tile * fp.tile_capacity;
-        for (uint32_t base = 0; base < count; base += TILE_THREADS) {
-            const uint32_t i = base + threadIdx.x;
-            RasterTri t;
-            bool have = i < count;
-            if (have) have = load_raster_tri(fp, list[i], t);
-            raster_batch<S>(fp, tc, have, t);
-        }
+        uint32_t count = min(fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE], fp.tile_capacity);
+        if (fp.debug_flags & 16u) count = min(count, 256u);
+        if (fp.debug_flags & 64u) count = min(count, 512u);
+        const TileEntry* list = fp.tile_lists + (size_t)tile * fp.tile_stride;
+        raster_stream<S>(fp, tc, count, [&](uint32_t i, TileEntry& e) -> bool { e = list[i]; return true; });
         /* the pass-wide list: primitives spanning many tiles, and spill of full tile lists */
         const uint32_t n_large = min(fp.counters[CTR_LARGE], fp.large_capacity);
-        for (uint32_t base = 0; base < n_large; base += TILE_THREADS) {
-            const uint32_t i = base + threadIdx.x;
-            RasterTri t;
-            bool have = i < n_large;
-            if (have) {
-                const LargeEntry le = fp.large_list[i];
-                const int bx0 = le.box & 255u, by0 = (le.box >> 8) & 255u, bx1 = (le.box >> 16) & 255u, by1 = le.box >> 24;
-                have = tx >= bx0 && tx <= bx1 && ty >= by0 && ty <= by1;
-                if (have) have = load_raster_tri(fp, le.e, t);
-            }
-            raster_batch<S>(fp, tc, have, t);
-        }
+        raster_stream<S>(fp, tc, n_large, [&](uint32_t i, TileEntry& e) -> bool {
+            const LargeEntry le = fp.large_list[i];
+            const int bx0 = le.box & 255u, by0 = (le.box >> 8) & 255u, bx1 = (le.box >> 16) & 255u, by1 = le.box >> 24;
+            e = le.e;
+            return tx >= bx0 && tx <= bx1 && ty >= by0 && ty <= by1;
+        });
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t ovf = fp.counters[CTR_OVERFLOW];
@@ -856,7 +901,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
 /* One thread per pixel: shade the primitive that owns each sample (once per distinct fan
  * triangle), resolve, encode, store.  Workgroup = 32x8 pixels, lanes along x. */
 template <int S>
-__global__ __launch_bounds__(256) void k_shade(FrameParams fp)
+__global__ __launch_bounds__(256, (S == 1 ? 6 : 4)) void k_shade(FrameParams fp)
 {
     __shared__ ShadeTables tb;
     stage_tables(tb, fp.tables);
