@@ -557,7 +557,12 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
     return true;
 }
 
-constexpr int LANE_RASTER_MAX_PIXELS = 16; /* larger boxes are walked by the whole wave */
+/* Who walks a triangle's box.  A lane walking its own box costs the wave as many steps as the
+ * largest box among its lanes; the whole wave walking one box costs a fixed set-up per triangle.
+ * So: boxes up to LANE_PIXELS always go by lane; when at least a quarter of the wave holds larger
+ * boxes (a scene of mid-size triangles: the lanes are balanced anyway) every box goes by lane;
+ * otherwise the few large ones are taken by the whole wave. */
+constexpr int LANE_PIXELS = 64;
 
 /* One batch: every lane holds (at most) one triangle.  Small boxes are walked by their own lane;
  * the others are taken one at a time by the whole wave (ballot, broadcast, 8x8 blocks). */
@@ -567,7 +572,9 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
     int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
     const bool hit = have && tri_box_in_tile(fp, tc, t, x0, y0, x1, y1);
     const int area = hit ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
-    const bool by_lane = hit && area <= LANE_RASTER_MAX_PIXELS && tri_is_small(t);
+    const bool small = tri_is_small(t);
+    const int crowd = __popcll(__ballot(hit && area > LANE_PIXELS && small));
+    const bool by_lane = hit && small && (area <= LANE_PIXELS || crowd >= 16);
     if (fp.debug_flags & 128u) { if (hit && t.z[0] == 123.0f) tc.keys[0] = 0; return; }
     if (by_lane) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
     uint64_t big = __ballot(hit && !by_lane);

@@ -52,3 +52,10 @@ def test_config1_full(device, oracle):
     """BASELINE configs[1] at full size: 1920x1080, 1 002 528 triangles."""
     mism = compare(scenes.config1(), device, oracle, threads=16)
     assert mism == 0
+
+
+def test_config2_full(device, oracle):
+    """BASELINE configs[2] at full size: 3840x2160, 10 000 instanced meshes, ~4x overdraw,
+    submitted back to front (the worst case for early depth rejection)."""
+    mism = compare(scenes.config2(), device, oracle, threads=16)
+    assert mism == 0
