@@ -246,29 +246,60 @@ __device__ __forceinline__ float plane_distance(int k, const ClipV& v)
     }
 }
 
-/* Sutherland-Hodgman against near, far and the guard band; crossings are computed
- * from the inside end so a shared edge yields the same vertex from both sides */
-__device__ __noinline__ int clip_polygon(ClipV* poly, int n)
+/* Polygon storage of the clipper: two buffers of up to 12 vertices x 7 floats per thread, kept in
+ * LDS ([buffer][vertex][component][thread], so a wave's accesses are conflict free) instead of
+ * per-thread arrays, which would become scratch memory. */
+constexpr int CLIP_THREADS = 64;
+constexpr int CLIP_MAX_VERTS = 12;
+constexpr int CLIP_LDS_FLOATS = 2 * CLIP_MAX_VERTS * 7 * CLIP_THREADS;
+
+struct ClipStore {
+    float* base; /* LDS array + this thread's index */
+    __device__ __forceinline__ float* at(int buf, int i, int comp) const
+    {
+        return base + ((buf * CLIP_MAX_VERTS + i) * 7 + comp) * CLIP_THREADS;
+    }
+    __device__ __forceinline__ ClipV get(int buf, int i) const
+    {
+        ClipV v;
+        v.x = *at(buf, i, 0); v.y = *at(buf, i, 1); v.z = *at(buf, i, 2); v.w = *at(buf, i, 3);
+        v.b0 = *at(buf, i, 4); v.b1 = *at(buf, i, 5); v.b2 = *at(buf, i, 6);
+        return v;
+    }
+    __device__ __forceinline__ void put(int buf, int i, const ClipV& v) const
+    {
+        *at(buf, i, 0) = v.x; *at(buf, i, 1) = v.y; *at(buf, i, 2) = v.z; *at(buf, i, 3) = v.w;
+        *at(buf, i, 4) = v.b0; *at(buf, i, 5) = v.b1; *at(buf, i, 6) = v.b2;
+    }
+};
+
+/* Sutherland-Hodgman against near, far and the guard band; crossings are computed from the
+ * inside end so a shared edge yields the same vertex from both sides.  The polygon starts in
+ * buffer 0; returns the vertex count and the buffer holding the result (0 vertices: nothing left). */
+__device__ __forceinline__ int clip_polygon(const ClipStore& st, int n, int& buf)
 {
-    ClipV tmp[12];
+    buf = 0;
     for (int k = 0; k < 6; ++k) {
-        float d[12];
         bool any_out = false;
         for (int i = 0; i < n; ++i) {
-            d[i] = plane_distance(k, poly[i]);
-            if (!(d[i] >= 0.0f)) any_out = true;
+            if (!(plane_distance(k, st.get(buf, i)) >= 0.0f)) any_out = true;
         }
         if (!any_out) continue;
+        const int dst = buf ^ 1;
         int m = 0;
+        ClipV cur = st.get(buf, 0);
+        float dc = plane_distance(k, cur);
         for (int i = 0; i < n; ++i) {
-            int j = (i + 1 == n) ? 0 : i + 1;
-            bool in_i = d[i] >= 0.0f, in_j = d[j] >= 0.0f;
-            if (in_i) tmp[m++] = poly[i];
+            const int j = (i + 1 == n) ? 0 : i + 1;
+            const ClipV nxt = st.get(buf, j);
+            const float dn = plane_distance(k, nxt);
+            const bool in_i = dc >= 0.0f, in_j = dn >= 0.0f;
+            if (in_i) st.put(dst, m++, cur);
             if (in_i != in_j) {
-                const ClipV a = in_i ? poly[i] : poly[j];
-                const ClipV b = in_i ? poly[j] : poly[i];
-                float da = in_i ? d[i] : d[j], db = in_i ? d[j] : d[i];
-                float t = da / (da - db);
+                const ClipV a = in_i ? cur : nxt; /* inside end */
+                const ClipV b = in_i ? nxt : cur; /* outside end */
+                const float da = in_i ? dc : dn, db = in_i ? dn : dc;
+                const float t = da / (da - db);
                 ClipV r;
                 r.x = fma32(t, b.x - a.x, a.x);
                 r.y = fma32(t, b.y - a.y, a.y);
@@ -277,59 +308,59 @@ __device__ __noinline__ int clip_polygon(ClipV* poly, int n)
                 r.b0 = fma32(t, b.b0 - a.b0, a.b0);
                 r.b1 = fma32(t, b.b1 - a.b1, a.b1);
                 r.b2 = fma32(t, b.b2 - a.b2, a.b2);
-                tmp[m++] = r;
+                st.put(dst, m++, r);
             }
+            cur = nxt; dc = dn;
         }
         n = m;
-        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+        buf = dst;
         if (n < 3) return 0;
     }
     return n;
 }
 
-/* A clipped primitive expanded into its fan */
-struct ClipFan {
-    ClipV poly[12];
-    Projected pv[12];
-    int n; /* 0: nothing survives */
-};
-
-__device__ __noinline__ void build_clip_fan(const FrameParams& fp, const DrawStatic& d, const float* clip_m,
-                                           uint32_t i0, uint32_t i1, uint32_t i2, ClipFan& fan)
+/* Clips one primitive.  Returns the number of corners of the clipped polygon (0: nothing survives,
+ * or a corner cannot be projected) and the buffer that holds it. */
+__device__ __forceinline__ int build_clip_fan(const DrawStatic& d, const float* clip_m, uint32_t i0, uint32_t i1, uint32_t i2,
+                                              const ClipStore& st, int& buf)
 {
     const uint32_t idx[3] = {i0, i1, i2};
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
         float c[4];
         vs_position(d, clip_m, idx[k], c);
-        fan.poly[k].x = c[0]; fan.poly[k].y = c[1]; fan.poly[k].z = c[2]; fan.poly[k].w = c[3];
-        fan.poly[k].b0 = k == 0 ? 1.0f : 0.0f;
-        fan.poly[k].b1 = k == 1 ? 1.0f : 0.0f;
-        fan.poly[k].b2 = k == 2 ? 1.0f : 0.0f;
+        ClipV v;
+        v.x = c[0]; v.y = c[1]; v.z = c[2]; v.w = c[3];
+        v.b0 = k == 0 ? 1.0f : 0.0f; v.b1 = k == 1 ? 1.0f : 0.0f; v.b2 = k == 2 ? 1.0f : 0.0f;
+        st.put(0, k, v);
     }
-    int n = clip_polygon(fan.poly, 3);
-    if (n < 3) { fan.n = 0; return; }
+    const int n = clip_polygon(st, 3, buf);
+    if (n < 3) return 0;
     for (int i = 0; i < n; ++i) {
-        const ClipV& v = fan.poly[i];
-        if (!(v.w > 0.0f) || !finite32(v.x) || !finite32(v.y) || !finite32(v.z) || !finite32(v.w)) { fan.n = 0; return; }
-        fan.pv[i] = project(fp, v.x, v.y, v.z, v.w);
+        const ClipV v = st.get(buf, i);
+        if (!(v.w > 0.0f) || !finite32(v.x) || !finite32(v.y) || !finite32(v.z) || !finite32(v.w)) return 0;
     }
-    fan.n = n;
+    return n;
 }
 
-/* fan triangle k (1 <= k <= n-2): corners (0, k, k+1).  bary[slot][j] = weight of parent corner j */
-__device__ __forceinline__ bool fan_triangle(const ClipFan& fan, int k, uint32_t cull_mode, uint32_t front_face,
-                                             RTri& t, float bary[3][3])
+/* fan triangle k (1 <= k <= n-2): corners (0, k, k+1), projected, oriented, culled.
+ * bary[slot][j] = weight of the parent's corner j at the triangle's corner in that slot */
+__device__ __forceinline__ bool fan_triangle(const FrameParams& fp, const ClipStore& st, int buf, int k,
+                                             uint32_t cull_mode, uint32_t front_face, RTri& t, float bary[3][3])
 {
     const int c[3] = {0, k, k + 1};
+    ClipV cv[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        t.x[q] = fan.pv[c[q]].x; t.y[q] = fan.pv[c[q]].y; t.z[q] = fan.pv[c[q]].z; t.iw[q] = fan.pv[c[q]].iw;
+        cv[q] = st.get(buf, c[q]);
+        const Projected p = project(fp, cv[q].x, cv[q].y, cv[q].z, cv[q].w);
+        t.x[q] = p.x; t.y[q] = p.y; t.z[q] = p.z; t.iw[q] = p.iw;
         t.corner[q] = (uint8_t)q;
     }
     if (!setup_tri(t, cull_mode, front_face)) return false;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const ClipV& v = fan.poly[c[t.corner[q]]];
+        const ClipV& v = t.corner[q] == 0 ? cv[0] : (t.corner[q] == 1 ? cv[1] : cv[2]);
         bary[q][0] = v.b0; bary[q][1] = v.b1; bary[q][2] = v.b2;
     }
     return true;

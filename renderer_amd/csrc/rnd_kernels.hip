@@ -30,6 +30,19 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+/* Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  This bijection
+ * gives every XCD runs of `run` consecutive work ids (run 0 to XCD 0, run 1 to XCD 1, ...), so
+ * horizontal neighbours -- which gather the same vertices and texels -- meet in one L2 while the
+ * screen's rows stay spread over all XCDs for balance.  Ids past the last full group of 8 runs
+ * keep their own number.  Placement only: results do not depend on it. */
+__device__ __forceinline__ uint32_t xcd_runs(uint32_t id, uint32_t n, uint32_t run)
+{
+    const uint32_t group = 8u * run;
+    if (run == 0u || id >= (n / group) * group) return id;
+    const uint32_t g = id / group, r = id % group;
+    return g * group + (r & 7u) * run + (r >> 3);
+}
+
 __device__ __forceinline__ uint32_t pack_bbox(int tx0, int ty0, int tx1, int ty1)
 {
     return (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
@@ -346,8 +359,11 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp)
  * the near plane, the far plane or the guard band.  Kept out of the setup and tile kernels so
  * those carry no scratch memory. */
 
-__global__ __launch_bounds__(64) void k_clip(FrameParams fp)
+__global__ __launch_bounds__(CLIP_THREADS) void k_clip(FrameParams fp)
 {
+    __shared__ float lds_poly[CLIP_LDS_FLOATS];
+    ClipStore st;
+    st.base = lds_poly + threadIdx.x;
     const uint32_t n = min(fp.counters[CTR_CLIP], fp.clip_capacity);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = fp.clip_list[i];
@@ -356,27 +372,30 @@ __global__ __launch_bounds__(64) void k_clip(FrameParams fp)
         const DrawStatic& d = fp.draws[draw];
         const uint32_t* ip = d.ib + (size_t)tri * 3;
         const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
-        ClipFan fan;
-        build_clip_fan(fp, d, fp.derived[draw].clip_m, i0, i1, i2, fan);
-        if (fan.n < 3) continue;
-        const uint32_t count = (uint32_t)fan.n - 2u;
+        int buf = 0;
+        const int corners = build_clip_fan(d, fp.derived[draw].clip_m, i0, i1, i2, st, buf);
+        if (corners < 3) continue;
+        const uint32_t count = (uint32_t)corners - 2u;
         const uint32_t first = atomicAdd(&fp.counters[CTR_CLIP_TRIS], count);
         if (first + count > fp.clip_tri_capacity) { flag_overflow(fp, OVF_CLIP_TRIS); continue; }
         PrimRec pr = {first, 0u, 0u, draw | FLAG_CLIPPED};
         fp.prim_rec[slot] = pr;
-        for (int k = 1; k + 1 < fan.n; ++k) {
+        for (int k = 1; k + 1 < corners; ++k) {
             RTri t; float bary[3][3];
             ClipTri ct;
-            const bool ok = fan_triangle(fan, k, d.cull_mode, d.front_face, t, bary);
+            const bool ok = fan_triangle(fp, st, buf, k, d.cull_mode, d.front_face, t, bary);
             int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
             const bool vis = ok && pixel_box(fp, t, x0, y0, x1, y1);
+#pragma unroll
             for (int q = 0; q < 3; ++q) {
                 ct.x[q] = t.x[q]; ct.y[q] = t.y[q]; ct.z[q] = t.z[q]; ct.iw[q] = t.iw[q];
+#pragma unroll
                 for (int j = 0; j < 3; ++j) ct.bary[q * 3 + j] = ok ? bary[q][j] : 0.0f;
             }
             ct.v[0] = d.svtx_base + i0; ct.v[1] = d.svtx_base + i1; ct.v[2] = d.svtx_base + i2;
             ct.draw = draw;
             ct.valid = vis ? 1u : 0u;
+#pragma unroll
             for (int j = 0; j < 5; ++j) ct.pad[j] = 0;
             const uint32_t idx = first + (uint32_t)(k - 1);
             fp.clip_tris[idx] = ct;
@@ -852,7 +871,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
 {
     __shared__ unsigned long long keys[TILE_PIXELS * S];
 
-    const uint32_t tile = blockIdx.x * fp.shard_count + fp.shard_index;
+    const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, fp.tiles_x / fp.shard_count) * fp.shard_count + fp.shard_index;
     const int tx = (int)(tile % fp.tiles_x), ty = (int)(tile / fp.tiles_x);
     TileCtx tc;
     tc.px0 = tx * TILE_W; tc.py0 = ty * TILE_H;
@@ -913,7 +932,9 @@ __global__ __launch_bounds__(256, (S == 1 ? 6 : 4)) void k_shade(FrameParams fp)
     __shared__ ShadeTables tb;
     stage_tables(tb, fp.tables);
     __syncthreads();
-    const int x = (int)(blockIdx.x * 32u + (threadIdx.x & 31u)), y = (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
+    const uint32_t blocks_x = (fp.width + 31u) / 32u;
+    const uint32_t blk = xcd_runs(blockIdx.x, gridDim.x, blocks_x);
+    const int x = (int)((blk % blocks_x) * 32u + (threadIdx.x & 31u)), y = (int)((blk / blocks_x) * 8u + (threadIdx.x >> 5));
     if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) return;
     if (fp.shard_count > 1) {
         const uint32_t tile = (uint32_t)(y >> TILE_SHIFT) * fp.tiles_x + (uint32_t)(x >> TILE_SHIFT);
@@ -1027,7 +1048,7 @@ void launch_clip(const FrameParams& fp, uint32_t expected, hipStream_t s)
     uint32_t blocks = (expected + expected / 4 + 63) / 64;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(64), 0, s, fp);
+    hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(CLIP_THREADS), 0, s, fp);
 }
 
 void launch_tile(const FrameParams& fp, hipStream_t s)
@@ -1041,7 +1062,7 @@ void launch_tile(const FrameParams& fp, hipStream_t s)
 
 void launch_shade(const FrameParams& fp, hipStream_t s)
 {
-    const dim3 grid((fp.width + 31) / 32, (fp.height + 7) / 8);
+    const dim3 grid(((fp.width + 31) / 32) * ((fp.height + 7) / 8));
     if (fp.samples == 4) hipLaunchKernelGGL(k_shade<4>, grid, dim3(256), 0, s, fp);
     else hipLaunchKernelGGL(k_shade<1>, grid, dim3(256), 0, s, fp);
 }
