@@ -626,33 +626,6 @@ __device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vt
     out.uv[1] = shader == 0 ? 1.0f - v : v; /* dummy.vert.glsl:25 flips v */
 }
 
-/* perspective-correct weights over the parent's corners at a window position */
-__device__ __forceinline__ void parent_weights(const RTri& t, bool small, bool clipped, const float bary[3][3], int64_t px, int64_t py, float* lam)
-{
-    float b0, b1, b2;
-    if (small) {
-        /* extent below 32 pixels and the position at most a pixel outside the box: products fit 32 bits */
-        const int32_t qx = (int32_t)px, qy = (int32_t)py;
-        b0 = (float)((t.x[2] - t.x[1]) * (qy - t.y[1]) - (t.y[2] - t.y[1]) * (qx - t.x[1])) * t.inv_area;
-        b1 = (float)((t.x[0] - t.x[2]) * (qy - t.y[2]) - (t.y[0] - t.y[2]) * (qx - t.x[2])) * t.inv_area;
-        b2 = (float)((t.x[1] - t.x[0]) * (qy - t.y[0]) - (t.y[1] - t.y[0]) * (qx - t.x[0])) * t.inv_area;
-    } else {
-        b0 = (float)edge64(t.x[1], t.y[1], t.x[2], t.y[2], px, py) * t.inv_area;
-        b1 = (float)edge64(t.x[2], t.y[2], t.x[0], t.y[0], px, py) * t.inv_area;
-        b2 = (float)edge64(t.x[0], t.y[0], t.x[1], t.y[1], px, py) * t.inv_area;
-    }
-    float p0 = b0 * t.iw[0], p1 = b1 * t.iw[1], p2 = b2 * t.iw[2];
-    float den = (p0 + p1) + p2;
-    float rden = 1.0f / den;
-    float q[3] = {p0 * rden, p1 * rden, p2 * rden};
-    if (!clipped) {
-        lam[t.corner[0]] = q[0]; lam[t.corner[1]] = q[1]; lam[t.corner[2]] = q[2];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) lam[j] = fma32(q[2], bary[2][j], fma32(q[1], bary[1][j], q[0] * bary[0][j]));
-    }
-}
-
 __device__ __forceinline__ float interp(const float* lam, float a0, float a1, float a2)
 {
     return fma32(lam[2], a2, fma32(lam[1], a1, lam[0] * a0));
@@ -668,16 +641,28 @@ __device__ __forceinline__ int wrap_coord(int i, int n, uint32_t tiled)
 
 __device__ __forceinline__ void fetch_texel(const ShadeTables& tb, const TexDesc& t, const uint8_t* lv, int w, int x, int y, float* rgb)
 {
-    uint32_t p = *reinterpret_cast<const uint32_t*>(lv + ((size_t)y * (size_t)w + (size_t)x) * 4);
+    /* a level holds at most 16384 x 16384 texels: coordinates fit 24 bits, the byte offset 32 */
+    const uint32_t off = (__umul24((uint32_t)y, (uint32_t)w) + (uint32_t)x) << 2;
+    /* texels live in device memory: say so, or a pointer read from a descriptor costs a flat load */
+    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexel;
+    uint32_t p = *(GlobalTexel)(lv + off);
     uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u;
     if (t.srgb) { rgb[0] = tb.decode[r]; rgb[1] = tb.decode[g]; rgb[2] = tb.decode[b]; }
     else { rgb[0] = (float)r / 255.0f; rgb[1] = (float)g / 255.0f; rgb[2] = (float)b / 255.0f; }
 }
 
-__device__ void sample_level(const ShadeTables& tb, const TexDesc& t, uint32_t level, float u, float v, float* rgb)
+/* pointer into LDS, typed as such so a per-lane index compiles to a ds_read and not a flat load */
+typedef const __attribute__((address_space(3))) unsigned long long* LdsLevels;
+
+template <bool PASS_TEX>
+__device__ void sample_level(const ShadeTables& tb, const TexDesc& t, LdsLevels lds_levels, uint32_t level, float u, float v, float* rgb)
 {
     int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
-    const uint8_t* lv = t.level[level];
+    /* the level differs from lane to lane: its base comes from the copy of the pass texture's
+     * table in LDS when there is one, else from the descriptor in memory */
+    const uint8_t* lv;
+    if constexpr (PASS_TEX) lv = reinterpret_cast<const uint8_t*>(lds_levels[level]);
+    else lv = t.level[level];
     if (!finite32(u)) u = 0.0f;
     if (!finite32(v)) v = 0.0f;
     if (t.filter_linear) {
@@ -709,7 +694,8 @@ __device__ void sample_level(const ShadeTables& tb, const TexDesc& t, uint32_t l
 
 /* texture() with implicit derivatives: lod = log2(longest footprint axis), clamped to
  * [0, levels-1], trilinear (sampler of tools.cpp:60-82) */
-__device__ void sample_texture(const ShadeTables& tb, const TexDesc& t, float u, float v,
+template <bool PASS_TEX>
+__device__ void sample_texture(const ShadeTables& tb, const TexDesc& t, LdsLevels lds_levels, float u, float v,
                                float dudx, float dvdx, float dudy, float dvdy, float* rgb)
 {
     float w0 = (float)t.width, h0 = (float)t.height;
@@ -718,83 +704,168 @@ __device__ void sample_texture(const ShadeTables& tb, const TexDesc& t, float u,
     float lambda = 0.5f * lod_log2(fmaxf(rx, ry));
     float max_lod = (float)(t.levels - 1);
     lambda = fminf(fmaxf(lambda, 0.0f), max_lod);
-    if (!(lambda > 0.0f) || t.levels == 1) { sample_level(tb, t, 0, u, v, rgb); return; }
+    if (!(lambda > 0.0f) || t.levels == 1) { sample_level<PASS_TEX>(tb, t, lds_levels, 0, u, v, rgb); return; }
     if (t.filter_linear) {
         float fl = floorf(lambda);
         uint32_t lo = (uint32_t)fl;
         uint32_t hi = lo + 1 < t.levels ? lo + 1 : t.levels - 1;
         float frac = lambda - fl;
         float a[3], b[3];
-        sample_level(tb, t, lo, u, v, a);
-        sample_level(tb, t, hi, u, v, b);
+        sample_level<PASS_TEX>(tb, t, lds_levels, lo, u, v, a);
+        sample_level<PASS_TEX>(tb, t, lds_levels, hi, u, v, b);
 #pragma unroll
         for (int k = 0; k < 3; ++k) rgb[k] = fma32(frac, b[k] - a[k], a[k]);
     } else {
         float lv = ceilf(lambda + 0.5f) - 1.0f;
         lv = fminf(fmaxf(lv, 0.0f), max_lod);
-        sample_level(tb, t, (uint32_t)lv, u, v, rgb);
+        sample_level<PASS_TEX>(tb, t, lds_levels, (uint32_t)lv, u, v, rgb);
     }
 }
 
+/* Perspective-correct weights of a fragment over the three corners of its triangle, at the pixel
+ * centre and (when derivatives are wanted) at the pixel's two neighbours inside its 2x2 quad.
+ *
+ * The reference arithmetic orients the triangle (positive area), evaluates its three edge functions
+ * e at the point, and forms b = float(e) * (1 / float(area)), p = b * (1/w), q = p * (1 / (p0+p1+p2)).
+ * Here the edge functions are taken in the corners' own order: orienting negates all of them and
+ * the area, and a product of two negated factors rounds the same way, so b is unchanged; the only
+ * trace of the orientation is the order in which the denominator is summed (corners 0,2,1 when the
+ * area is negative).  A neighbour's edge values differ from the pixel's by a constant per edge.
+ * Triangles whose box spans less than 32 pixels fit 24-bit multiplies; the rest take 64 bits. */
+struct Corners {
+    int32_t x[3], y[3]; /* 24.8 window coordinates */
+    float iw[3];        /* 1/w */
+};
+
+struct EdgeFloats {
+    float inv_s;        /* 1 / signed doubled area */
+    bool swapped;       /* negative area */
+    float iw[3];
+};
+
+__device__ __forceinline__ void weights_at(const EdgeFloats& t, float e0, float e1, float e2, float* q)
+{
+    const float p0 = (e0 * t.inv_s) * t.iw[0];
+    const float p1 = (e1 * t.inv_s) * t.iw[1];
+    const float p2 = (e2 * t.inv_s) * t.iw[2];
+    const float den = (p0 + (t.swapped ? p2 : p1)) + (t.swapped ? p1 : p2);
+    const float rden = 1.0f / den;
+    q[0] = p0 * rden; q[1] = p1 * rden; q[2] = p2 * rden;
+}
+
+/* q, qx, qy: weights at pixel (x, y), at its quad neighbour in x and at its quad neighbour in y */
+__device__ __forceinline__ void corner_weights(const Corners& c, int x, int y, bool want_derivs, float* q, float* qnx, float* qny)
+{
+    const int32_t dx0 = c.x[2] - c.x[1], dy0 = c.y[2] - c.y[1];
+    const int32_t dx1 = c.x[0] - c.x[2], dy1 = c.y[0] - c.y[2];
+    const int32_t dx2 = c.x[1] - c.x[0], dy2 = c.y[1] - c.y[0];
+    const int32_t px = x * 256 + 128, py = y * 256 + 128;
+    const bool left = (x & 1) != 0, up = (y & 1) != 0; /* the neighbour is at x-1 / y-1 */
+    const int ext = max(max(c.x[0], max(c.x[1], c.x[2])) - min(c.x[0], min(c.x[1], c.x[2])),
+                        max(c.y[0], max(c.y[1], c.y[2])) - min(c.y[0], min(c.y[1], c.y[2])));
+    float fe[3], fx[3] = {0.f, 0.f, 0.f}, fy[3] = {0.f, 0.f, 0.f}, fs;
+    /* a shaded pixel has a sample inside the triangle, so it and its quad neighbours are within two
+     * pixels of the box: with a box under 2^13 every factor below stays under 2^14 */
+    if (ext < (1 << 13)) {
+        const int32_t e0 = __mul24(dx0, py - c.y[1]) - __mul24(dy0, px - c.x[1]);
+        const int32_t e1 = __mul24(dx1, py - c.y[2]) - __mul24(dy1, px - c.x[2]);
+        const int32_t e2 = __mul24(dx2, py - c.y[0]) - __mul24(dy2, px - c.x[0]);
+        fs = (float)(__mul24(dx2, c.y[2] - c.y[0]) - __mul24(dy2, c.x[2] - c.x[0]));
+        fe[0] = (float)e0; fe[1] = (float)e1; fe[2] = (float)e2;
+        if (want_derivs) {
+            /* x by +-256 changes e by -+256*dy; y by +-256 changes e by +-256*dx */
+            const int32_t gx0 = dy0 << 8, gx1 = dy1 << 8, gx2 = dy2 << 8, gy0 = dx0 << 8, gy1 = dx1 << 8, gy2 = dx2 << 8;
+            fx[0] = (float)(left ? e0 + gx0 : e0 - gx0); fx[1] = (float)(left ? e1 + gx1 : e1 - gx1); fx[2] = (float)(left ? e2 + gx2 : e2 - gx2);
+            fy[0] = (float)(up ? e0 - gy0 : e0 + gy0); fy[1] = (float)(up ? e1 - gy1 : e1 + gy1); fy[2] = (float)(up ? e2 - gy2 : e2 + gy2);
+        }
+    } else {
+        const int64_t e0 = (int64_t)dx0 * (py - c.y[1]) - (int64_t)dy0 * (px - c.x[1]);
+        const int64_t e1 = (int64_t)dx1 * (py - c.y[2]) - (int64_t)dy1 * (px - c.x[2]);
+        const int64_t e2 = (int64_t)dx2 * (py - c.y[0]) - (int64_t)dy2 * (px - c.x[0]);
+        fs = (float)((int64_t)dx2 * (c.y[2] - c.y[0]) - (int64_t)dy2 * (c.x[2] - c.x[0]));
+        fe[0] = (float)e0; fe[1] = (float)e1; fe[2] = (float)e2;
+        if (want_derivs) {
+            const int64_t gx0 = (int64_t)dy0 * 256, gx1 = (int64_t)dy1 * 256, gx2 = (int64_t)dy2 * 256;
+            const int64_t gy0 = (int64_t)dx0 * 256, gy1 = (int64_t)dx1 * 256, gy2 = (int64_t)dx2 * 256;
+            fx[0] = (float)(left ? e0 + gx0 : e0 - gx0); fx[1] = (float)(left ? e1 + gx1 : e1 - gx1); fx[2] = (float)(left ? e2 + gx2 : e2 - gx2);
+            fy[0] = (float)(up ? e0 - gy0 : e0 + gy0); fy[1] = (float)(up ? e1 - gy1 : e1 + gy1); fy[2] = (float)(up ? e2 - gy2 : e2 + gy2);
+        }
+    }
+    EdgeFloats t;
+    t.swapped = fs < 0.0f;
+    t.inv_s = 1.0f / fs;
+    t.iw[0] = c.iw[0]; t.iw[1] = c.iw[1]; t.iw[2] = c.iw[2];
+    weights_at(t, fe[0], fe[1], fe[2], q);
+    if (want_derivs) {
+        weights_at(t, fx[0], fx[1], fx[2], qnx);
+        weights_at(t, fy[0], fy[1], fy[2], qny);
+    }
+}
+
+/* weights over a fan triangle's corners -> weights over its parent's corners */
+__device__ __forceinline__ void to_parent(const float* bary, float* q)
+{
+    float lam[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) lam[j] = fma32(q[2], bary[6 + j], fma32(q[1], bary[3 + j], q[0] * bary[j]));
+    q[0] = lam[0]; q[1] = lam[1]; q[2] = lam[2];
+}
+
 /* colour of the fragment of (slot, sub) at pixel (x, y) */
-__device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, uint32_t slot, uint32_t sub, int x, int y, float* rgba)
+__device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
+                            uint32_t slot, uint32_t sub, int x, int y, float* rgba)
 {
     const PrimRec pr = fp.prim_rec[slot];
     const bool clipped = (pr.draw_flags & FLAG_CLIPPED) != 0u;
-    RTri t;
-    float bary[3][3];
-    uint32_t vtx[3];
-    uint32_t draw;
-    if (!clipped) {
-        draw = pr.draw_flags & SLOT_MASK;
-        vtx[0] = pr.v0; vtx[1] = pr.v1; vtx[2] = pr.v2;
-        const SVtx a = fp.svtx[pr.v0], b = fp.svtx[pr.v1], c = fp.svtx[pr.v2];
-        t.x[0] = a.xf >> 8; t.y[0] = a.y; t.z[0] = a.z; t.iw[0] = a.iw; t.corner[0] = 0;
-        t.x[1] = b.xf >> 8; t.y[1] = b.y; t.z[1] = b.z; t.iw[1] = b.iw; t.corner[1] = 1;
-        t.x[2] = c.xf >> 8; t.y[2] = c.y; t.z[2] = c.z; t.iw[2] = c.iw; t.corner[2] = 2;
-        setup_tri(t, 0u, 0u); /* orientation only: the primitive already passed culling */
-    } else {
+    uint32_t vtx[3] = {pr.v0, pr.v1, pr.v2};
+    uint32_t draw = pr.draw_flags & SLOT_MASK;
+    if (clipped) {
         const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
         draw = ct->draw;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            t.x[k] = ct->x[k]; t.y[k] = ct->y[k]; t.z[k] = ct->z[k]; t.iw[k] = ct->iw[k]; t.corner[k] = (uint8_t)k;
-            bary[k][0] = ct->bary[k * 3 + 0]; bary[k][1] = ct->bary[k * 3 + 1]; bary[k][2] = ct->bary[k * 3 + 2];
-            vtx[k] = ct->v[k];
-        }
-        t.area2 = edge64(t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2]);
-        t.inv_area = 1.0f / (float)t.area2;
+        vtx[0] = ct->v[0]; vtx[1] = ct->v[1]; vtx[2] = ct->v[2];
     }
     /* shader and texture come from the kernel arguments when every draw of the pass agrees,
      * which saves two dependent loads per pixel; otherwise from the draw's record */
     const int shader = fp.pass_shader >= 0 ? fp.pass_shader : fp.draws[draw].shader;
+    int texture = -1;
+    if (shader == 0 || shader == 1) texture = fp.pass_texture != -2 ? fp.pass_texture : fp.draws[draw].texture;
+    const bool want_derivs = texture >= 0;
     Varyings v0, v1, v2;
     load_varyings(fp, vtx[0], shader, v0);
     load_varyings(fp, vtx[1], shader, v1);
     load_varyings(fp, vtx[2], shader, v2);
-    const int64_t px = (int64_t)x * 256 + 128, py = (int64_t)y * 256 + 128;
-    const int ext = max(max(t.x[0], max(t.x[1], t.x[2])) - min(t.x[0], min(t.x[1], t.x[2])),
-                        max(t.y[0], max(t.y[1], t.y[2])) - min(t.y[0], min(t.y[1], t.y[2])));
-    /* a shaded pixel has a sample inside the triangle, so it and its quad neighbours are within
-     * two pixels of the box */
-    const bool small = ext < (1 << 13);
-    float lam[3];
-    parent_weights(t, small, clipped, bary, px, py, lam);
+
+    /* weights over the parent's corners at the pixel centre, and at the neighbour in x and the
+     * neighbour in y of the 2x2 quad (same primitive, extrapolated) for the derivatives */
+    float lam[3], lnx[3] = {0.f, 0.f, 0.f}, lny[3] = {0.f, 0.f, 0.f};
+    Corners c;
+    if (!clipped) {
+        const SVtx p0 = fp.svtx[vtx[0]], p1 = fp.svtx[vtx[1]], p2 = fp.svtx[vtx[2]];
+        c.x[0] = p0.xf >> 8; c.y[0] = p0.y; c.iw[0] = p0.iw;
+        c.x[1] = p1.xf >> 8; c.y[1] = p1.y; c.iw[1] = p1.iw;
+        c.x[2] = p2.xf >> 8; c.y[2] = p2.y; c.iw[2] = p2.iw;
+    } else {
+        const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { c.x[k] = ct->x[k]; c.y[k] = ct->y[k]; c.iw[k] = ct->iw[k]; }
+    }
+    corner_weights(c, x, y, want_derivs, lam, lnx, lny);
+    if (clipped) {
+        const float* bary = fp.clip_tris[pr.v0 + sub].bary;
+        to_parent(bary, lam);
+        if (want_derivs) { to_parent(bary, lnx); to_parent(bary, lny); }
+    }
+
     float tex[3] = {1.0f, 1.0f, 1.0f};
     if (shader == 0 || shader == 1) {
-        const int texture = fp.pass_texture != -2 ? fp.pass_texture : fp.draws[draw].texture;
         if (texture >= 0) {
             float u = interp(lam, v0.uv[0], v1.uv[0], v2.uv[0]), v = interp(lam, v0.uv[1], v1.uv[1], v2.uv[1]);
-            /* derivatives inside the 2x2 pixel quad: the neighbour in x and the neighbour in y, same primitive */
-            float lnx[3], lny[3];
-            parent_weights(t, small, clipped, bary, (int64_t)(x ^ 1) * 256 + 128, py, lnx);
-            parent_weights(t, small, clipped, bary, px, (int64_t)(y ^ 1) * 256 + 128, lny);
             float unx = interp(lnx, v0.uv[0], v1.uv[0], v2.uv[0]), vnx = interp(lnx, v0.uv[1], v1.uv[1], v2.uv[1]);
             float uny = interp(lny, v0.uv[0], v1.uv[0], v2.uv[0]), vny = interp(lny, v0.uv[1], v1.uv[1], v2.uv[1]);
             float dudx = (x & 1) ? u - unx : unx - u, dvdx = (x & 1) ? v - vnx : vnx - v;
             float dudy = (y & 1) ? u - uny : uny - u, dvdy = (y & 1) ? v - vny : vny - v;
-            if (fp.pass_texture >= 0) sample_texture(tb, fp.pass_tex, u, v, dudx, dvdx, dudy, dvdy, tex);
-            else sample_texture(tb, fp.textures[texture], u, v, dudx, dvdx, dudy, dvdy, tex);
+            if (fp.pass_texture >= 0) sample_texture<true>(tb, fp.pass_tex, pass_levels, u, v, dudx, dvdx, dudy, dvdy, tex);
+            else sample_texture<false>(tb, fp.textures[texture], nullptr, u, v, dudx, dvdx, dudy, dvdy, tex);
         } else {
             tex[0] = tex[1] = tex[2] = 0.0f;
         }
@@ -926,11 +997,16 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
 
 /* One thread per pixel: shade the primitive that owns each sample (once per distinct fan
  * triangle), resolve, encode, store.  Workgroup = 32x8 pixels, lanes along x. */
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 6 /* waves per SIMD the single-sample shading kernel is compiled for */
+#endif
 template <int S>
-__global__ __launch_bounds__(256, (S == 1 ? 6 : 4)) void k_shade(FrameParams fp)
+__global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(FrameParams fp)
 {
     __shared__ ShadeTables tb;
+    __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
     stage_tables(tb, fp.tables);
+    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
     __syncthreads();
     const uint32_t blocks_x = (fp.width + 31u) / 32u;
     const uint32_t blk = xcd_runs(blockIdx.x, gridDim.x, blocks_x);
@@ -961,7 +1037,7 @@ __global__ __launch_bounds__(256, (S == 1 ? 6 : 4)) void k_shade(FrameParams fp)
         } else if (fp.debug_flags & 1u) {
             smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.5f;
         } else {
-            shade_pixel(fp, tb, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, x, y, smp[s]);
+            shade_pixel(fp, tb, (LdsLevels)pass_levels, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, x, y, smp[s]);
         }
     }
     float acc[4];
