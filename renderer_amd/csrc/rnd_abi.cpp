@@ -76,6 +76,9 @@ struct rnd_device_t {
     bool stage_used[STAGE_SLOTS] = {};
     int stage_next = 0;
     uint32_t* status_host = nullptr; /* pinned word the tile kernel writes when a work list overflowed */
+    /* the latest small write to a uniform buffer, held back until the next submit carries it in
+     * its kernel arguments (or until something else needs the buffer's bytes in memory) */
+    UniformPatch pending = {};
     bool profiling = false;
     hipEvent_t ev[RND_STAGE_COUNT + 1] = {};
     float stage_ms[RND_STAGE_COUNT] = {};
@@ -186,6 +189,29 @@ int set_device(rnd_device dev)
 }
 
 /* after the stream has been waited for: did a frame overflow one of its work lists? */
+/* stream-ordered small upload through the pinned ring: returns without waiting for the device */
+int staged_write(rnd_device dev, uint8_t* dst, const void* src, size_t bytes)
+{
+    int slot = dev->stage_next;
+    dev->stage_next = (slot + 1) % rnd_device_t::STAGE_SLOTS;
+    if (dev->stage_used[slot]) HIP_TRY(hipEventSynchronize(dev->stage_ev[slot]));
+    uint8_t* staging = dev->stage_host + (size_t)slot * rnd_device_t::STAGE_SLOT_BYTES;
+    memcpy(staging, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, staging, bytes, hipMemcpyHostToDevice, dev->stream));
+    HIP_TRY(hipEventRecord(dev->stage_ev[slot], dev->stream));
+    dev->stage_used[slot] = true;
+    return RND_SUCCESS;
+}
+
+/* puts a held-back uniform write on the stream as an ordinary copy */
+int flush_pending(rnd_device dev)
+{
+    if (!dev->pending.dst) return RND_SUCCESS;
+    UniformPatch p = dev->pending;
+    dev->pending.dst = nullptr;
+    return staged_write(dev, p.dst, p.words, p.bytes);
+}
+
 int report_overflow(rnd_device dev)
 {
     if (!dev->status_host || !*dev->status_host) return RND_SUCCESS;
@@ -385,18 +411,20 @@ int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t 
     if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write: range outside the buffer");
     if (int r = set_device(buf->dev)) return r;
     rnd_device dev = buf->dev;
-    if (bytes <= rnd_device_t::STAGE_SLOT_BYTES) {
-        /* stream-ordered after earlier submits: a frame already queued still sees the old bytes */
-        int slot = dev->stage_next;
-        dev->stage_next = (slot + 1) % rnd_device_t::STAGE_SLOTS;
-        if (dev->stage_used[slot]) HIP_TRY(hipEventSynchronize(dev->stage_ev[slot]));
-        uint8_t* staging = dev->stage_host + (size_t)slot * rnd_device_t::STAGE_SLOT_BYTES;
-        memcpy(staging, src, (size_t)bytes);
-        HIP_TRY(hipMemcpyAsync(buf->ptr + offset, staging, (size_t)bytes, hipMemcpyHostToDevice, dev->stream));
-        HIP_TRY(hipEventRecord(dev->stage_ev[slot], dev->stream));
-        dev->stage_used[slot] = true;
+    /* stream-ordered after earlier submits: a frame already queued still sees the old bytes */
+    if ((buf->usage & RND_BUFFER_USAGE_UNIFORM) && bytes <= PATCH_MAX_BYTES && bytes % 4 == 0 && offset % 4 == 0) {
+        /* the per-frame uniform block (base_obj_viewer_app.cpp:134-138): no copy is queued; the
+         * next submit takes the bytes along in its kernel arguments */
+        uint8_t* dst = buf->ptr + offset;
+        if (dev->pending.dst && !(dev->pending.dst == dst && dev->pending.bytes == (uint32_t)bytes))
+            if (int r = flush_pending(dev)) return r;
+        dev->pending.dst = dst;
+        dev->pending.bytes = (uint32_t)bytes;
+        memcpy(dev->pending.words, src, (size_t)bytes);
         return RND_SUCCESS;
     }
+    if (int r = flush_pending(dev)) return r;
+    if (bytes <= rnd_device_t::STAGE_SLOT_BYTES) return staged_write(dev, buf->ptr + offset, src, (size_t)bytes);
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, src, (size_t)bytes, hipMemcpyHostToDevice, dev->stream));
     HIP_TRY(hipStreamSynchronize(dev->stream));
     return RND_SUCCESS;
@@ -407,6 +435,7 @@ int rnd_buffer_write_device(rnd_buffer buf, uint64_t offset, const void* device_
     if (!buf || !device_src) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write_device: bad arguments");
     if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write_device: range outside the buffer");
     if (int r = set_device(buf->dev)) return r;
+    if (int r = flush_pending(buf->dev)) return r;
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, device_src, (size_t)bytes, hipMemcpyDeviceToDevice, buf->dev->stream));
     return RND_SUCCESS;
 }
@@ -416,6 +445,7 @@ int rnd_buffer_read(rnd_buffer buf, uint64_t offset, void* dst, uint64_t bytes)
     if (!buf || !dst) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_read: bad arguments");
     if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_read: range outside the buffer");
     if (int r = set_device(buf->dev)) return r;
+    if (int r = flush_pending(buf->dev)) return r;
     HIP_TRY(hipStreamSynchronize(buf->dev->stream));
     HIP_TRY(hipMemcpy(dst, buf->ptr + offset, (size_t)bytes, hipMemcpyDeviceToHost));
     return RND_SUCCESS;
@@ -425,6 +455,8 @@ int rnd_buffer_destroy(rnd_buffer buf)
 {
     if (!buf) return RND_SUCCESS;
     (void)hipSetDevice(buf->dev->ordinal);
+    /* a held-back write into this buffer has nowhere to go any more */
+    if (buf->dev->pending.dst >= buf->ptr && buf->dev->pending.dst < buf->ptr + buf->bytes) buf->dev->pending.dst = nullptr;
     (void)hipStreamSynchronize(buf->dev->stream);
     (void)hipFree(buf->ptr);
     delete buf;
@@ -910,6 +942,9 @@ int rnd_cmd_end(rnd_cmd cmd)
     HIP_TRY(cmd->d_clip_list.resize(clip_cap));
     HIP_TRY(cmd->d_clip_tris.resize(clip_tri_cap));
     HIP_TRY(cmd->d_counters.resize(CTR_COUNT));
+    /* every frame leaves its counters at zero for the next one; the first frame needs them so */
+    HIP_TRY(hipMemset(cmd->d_tile_count.ptr, 0, n_tiles * TILE_COUNT_STRIDE * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(cmd->d_counters.ptr, 0, CTR_COUNT * sizeof(uint32_t)));
 
     FrameParams& fp = cmd->fp;
     memset(&fp, 0, sizeof(fp));
@@ -993,9 +1028,9 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     hipStream_t s = dev->stream;
     const bool prof = dev->profiling;
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CONSTANTS], s));
-    launch_constants(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_VERTEX], s));
-    launch_vertex(fp, s);
+    launch_vertex(fp, dev->pending, s);
+    dev->pending.dst = nullptr;
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SETUP], s));
     launch_setup(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CLIP], s));

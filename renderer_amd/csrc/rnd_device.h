@@ -21,6 +21,13 @@
 namespace rnd {
 
 __device__ __forceinline__ float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+/* Pointers read from a record in memory (a draw's vertex, index and uniform buffers) are device
+ * memory; saying so lets the load be a global one instead of a flat one. */
+typedef const __attribute__((address_space(1))) float* GlobalF32;
+typedef const __attribute__((address_space(1))) uint32_t* GlobalU32;
+__device__ __forceinline__ float load_f32(const float* p) { return *(GlobalF32)p; }
+__device__ __forceinline__ uint32_t load_u32(const uint32_t* p) { return *(GlobalU32)p; }
 __device__ __forceinline__ bool finite32(float v) { return fabsf(v) <= 3.4028234663852886e38f; }
 
 /* window coordinate -> 24.8: floor(fma(v, 256, 0.5)) */
@@ -179,7 +186,7 @@ __device__ __forceinline__ Projected project(const FrameParams& fp, float x, flo
 __device__ __forceinline__ void vs_position(const DrawStatic& d, const float* clip_m, uint32_t v, float* clip)
 {
     const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_pos);
-    mat4_point(clip_m, p[0], p[1], p[2], clip);
+    mat4_point(clip_m, load_f32(p), load_f32(p + 1), load_f32(p + 2), clip);
     clip[1] = 1.0f - clip[1];
 }
 

@@ -121,10 +121,21 @@ struct DrawStatic {
     float push[20];      /* vec4 colour, mat4 transform */
 };
 
-/* Per-draw matrices derived from the uniform buffer each time the work executes */
+/* Per-draw matrix derived from the uniform buffer each time the work executes: object space to
+ * clip space.  The vertex kernel builds it per wave and stores it here for the clipper. */
 struct DrawDerived {
     float clip_m[16];
-    float nrm_m[12];
+};
+
+/* A small host write to a uniform buffer that has not reached device memory yet.  It rides in
+ * the arguments of the next frame's first kernel, which reads the buffer through it and also
+ * stores it, so the per-frame 320-byte update costs no copy of its own. */
+constexpr uint32_t PATCH_MAX_BYTES = 512;
+struct UniformPatch {
+    uint8_t* dst;       /* device address the bytes belong at (4-byte aligned), or null */
+    uint32_t bytes;     /* multiple of 4 */
+    uint32_t pad;
+    uint32_t words[PATCH_MAX_BYTES / 4];
 };
 
 struct Chunk {
@@ -189,8 +200,7 @@ struct FrameParams {
 
 /* launch wrappers (rnd_kernels.hip) */
 void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n_jobs, hipStream_t s);
-void launch_constants(const FrameParams& fp, hipStream_t s);
-void launch_vertex(const FrameParams& fp, hipStream_t s);
+void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s);
 void launch_setup(const FrameParams& fp, hipStream_t s);
 void launch_clip(const FrameParams& fp, uint32_t expected, hipStream_t s);
 void launch_tile(const FrameParams& fp, hipStream_t s);

@@ -65,9 +65,8 @@ struct PrimFetch {
 /* false: an index points outside the vertex buffer, the primitive is dropped */
 __device__ __forceinline__ bool fetch_prim(const FrameParams& fp, const DrawStatic& d, uint32_t tri, PrimFetch& pf)
 {
-    struct Idx3 { uint32_t a, b, c; };
-    const Idx3 ix = *reinterpret_cast<const Idx3*>(d.ib + (size_t)tri * 3); /* one 12-byte load */
-    pf.idx[0] = ix.a; pf.idx[1] = ix.b; pf.idx[2] = ix.c;
+    const uint32_t* ip = d.ib + (size_t)tri * 3; /* three adjacent words: the compiler merges them into one 12-byte load */
+    pf.idx[0] = load_u32(ip); pf.idx[1] = load_u32(ip + 1); pf.idx[2] = load_u32(ip + 2);
     if (pf.idx[0] >= d.vert_count || pf.idx[1] >= d.vert_count || pf.idx[2] >= d.vert_count) return false;
     const SVtx* sv = fp.svtx + d.svtx_base;
     pf.v[0] = sv[pf.idx[0]]; pf.v[1] = sv[pf.idx[1]]; pf.v[2] = sv[pf.idx[2]];
@@ -130,44 +129,92 @@ __global__ __launch_bounds__(256) void k_index_range(const IndexRangeJob* jobs, 
     if (any) atomicMax(&out_max[blockIdx.y], m);
 }
 
-/* ------------------------------------------------------------------ per-draw matrices */
-
-/* first kernel of a frame: clears this frame's tile counters and list counters, and builds
- * the per-draw matrices from the uniform buffer as it is when the frame executes */
-__global__ __launch_bounds__(64) void k_constants(FrameParams fp)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < fp.tiles_x * fp.tiles_y) fp.tile_count[(size_t)i * TILE_COUNT_STRIDE] = 0;
-    if (i < CTR_COUNT) fp.counters[i] = 0;
-    if (i >= fp.n_draws) return;
-    const DrawStatic& d = fp.draws[i];
-    DrawDerived out;
-    float mvp[16], model[16], tr[16];
-    for (int k = 0; k < 16; ++k) { mvp[k] = d.ubo[64 + k]; model[k] = d.ubo[48 + k]; tr[k] = d.push[4 + k]; }
-    if (d.shader == 0) {
-        for (int k = 0; k < 16; ++k) out.clip_m[k] = mvp[k];
-        for (int k = 0; k < 12; ++k) out.nrm_m[k] = 0.0f;
-    } else {
-        float mt[16];
-        mat4_mul_pinned(mvp, tr, out.clip_m);
-        mat4_mul_pinned(model, tr, mt);
-        normal_matrix(mt, out.nrm_m);
-        out.nrm_m[9] = out.nrm_m[10] = out.nrm_m[11] = 0.0f;
-    }
-    fp.derived[i] = out;
-}
-
 /* ------------------------------------------------------------------ vertex kernel */
 
-__global__ __launch_bounds__(256) void k_vertex(FrameParams fp)
+/* a float of a uniform buffer as the frame must see it: from the pending host write when that
+ * covers the address, else from memory */
+struct VertexArgs {
+    FrameParams fp;
+    UniformPatch up;
+};
+
+__device__ __forceinline__ float uniform_read(const UniformPatch& up, const float* p)
 {
+    const size_t off = (size_t)(reinterpret_cast<const uint8_t*>(p) - up.dst);
+    if (up.dst && off < (size_t)up.bytes) {
+        /* the words are indexed per lane: read them where the kernel arguments already are in
+         * memory (VertexArgs is the kernel's only argument), so the compiler need not copy
+         * the block into private memory to index it */
+        typedef const __attribute__((address_space(4))) uint32_t* KernargWords;
+        KernargWords w = (KernargWords)((const __attribute__((address_space(4))) uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                        offsetof(VertexArgs, up) + offsetof(UniformPatch, words));
+        return __uint_as_float(w[off >> 2]);
+    }
+    return load_f32(p);
+}
+
+__device__ __forceinline__ float lane_value(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+/* The draw's matrices, built by the wave from the uniform buffer as it is when the frame executes
+ * (base_obj_viewer_app.cpp:126-138 writes it every frame): clip_m = mvp * push.transform and the
+ * normal matrix inverse(transpose(mat3(model * push.transform))) (test_ktx.vert:28-30); the dummy
+ * shader uses mvp alone (dummy.vert.glsl:22).  Lane k < 16 computes element k of the first product,
+ * lane 16 + k element k of the second, each as the same four-term multiply-add chain a scalar
+ * implementation runs; the results are then broadcast. */
+__device__ __forceinline__ void wave_matrices(const UniformPatch& up, const DrawStatic& d, float* clip_m, float* nrm_m, float& my_element)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t k = lane & 15u, row = k & 3u, col = k >> 2;
+    float acc;
+    if (d.shader == 0) {
+        acc = uniform_read(up, d.ubo + 64 + k);
+    } else {
+        const float* a = d.ubo + ((lane & 16u) ? 48 : 64); /* model : mvp */
+        const float* b = d.push + 4 + col * 4;
+        acc = uniform_read(up, a + 0 * 4 + row) * b[0];
+        acc = fma32(uniform_read(up, a + 1 * 4 + row), b[1], acc);
+        acc = fma32(uniform_read(up, a + 2 * 4 + row), b[2], acc);
+        acc = fma32(uniform_read(up, a + 3 * 4 + row), b[3], acc);
+    }
+    my_element = acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) clip_m[i] = lane_value(acc, i);
+    if (d.shader == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) nrm_m[i] = 0.0f;
+    } else {
+        float mt[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mt[i] = 0.0f;
+        mt[0] = lane_value(acc, 16); mt[1] = lane_value(acc, 17); mt[2] = lane_value(acc, 18);
+        mt[4] = lane_value(acc, 20); mt[5] = lane_value(acc, 21); mt[6] = lane_value(acc, 22);
+        mt[8] = lane_value(acc, 24); mt[9] = lane_value(acc, 25); mt[10] = lane_value(acc, 26);
+        normal_matrix(mt, nrm_m);
+    }
+}
+
+/* One wave per chunk of 64 vertices of one draw.  First kernel of a frame: workgroup 0 also lands
+ * the pending uniform write in memory. */
+__global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
+{
+    const FrameParams& fp = args.fp;
+    const UniformPatch& up = args.up;
+    if (blockIdx.x == 0 && up.dst) {
+        for (uint32_t i = threadIdx.x; i < up.bytes / 4u; i += blockDim.x)
+            reinterpret_cast<uint32_t*>(up.dst)[i] = __float_as_uint(uniform_read(up, reinterpret_cast<const float*>(up.dst) + i));
+    }
     uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_vchunks) return;
     const Chunk c = fp.vchunks[chunk];
     const DrawStatic& d = fp.draws[c.draw];
+    float m[16], nm[9], mine;
+    wave_matrices(up, d, m, nm, mine);
+    if (c.first == 0 && lane_id() < 16u) fp.derived[c.draw].clip_m[lane_id()] = mine;
     uint32_t v = c.first + lane_id();
     if (v >= d.vert_count) return;
-    const float* m = fp.derived[c.draw].clip_m;
     float clip[4];
     vs_position(d, m, v, clip);
     uint32_t oc = outcode(clip[0], clip[1], clip[2], clip[3]);
@@ -187,19 +234,19 @@ __global__ __launch_bounds__(256) void k_vertex(FrameParams fp)
     vo.nx = vo.ny = vo.nz = 0.0f; vo.u = vo.v = 0.0f; vo.pad[0] = vo.pad[1] = vo.pad[2] = 0.0f;
     if (d.off_uv >= 0) {
         const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_uv);
-        vo.u = p[0]; vo.v = p[1];
+        vo.u = load_f32(p); vo.v = load_f32(p + 1);
     }
     if (d.shader != 0) {
         float nrm[3] = {0.0f, 0.0f, 0.0f};
         if (d.off_nrm >= 0) {
             const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_nrm);
-            nrm[0] = p[0]; nrm[1] = p[1]; nrm[2] = p[2];
+            nrm[0] = load_f32(p); nrm[1] = load_f32(p + 1); nrm[2] = load_f32(p + 2);
         }
         const float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
         const float len = sqrtf(len2);
         const float nn[3] = {nrm[0] / len, nrm[1] / len, nrm[2] / len};
         float tn[3];
-        mat3_vec(fp.derived[c.draw].nrm_m, nn, tn);
+        mat3_vec(nm, nn, tn);
         vo.nx = tn[0]; vo.ny = tn[1]; vo.nz = tn[2];
     }
     fp.svary[d.svtx_base + v] = vo;
@@ -977,6 +1024,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
         fp.status_host[1] = fp.counters[CTR_CLIP]; /* sizes the next frame's clip launch */
     }
     __syncthreads();
+    /* every thread has read the list length: leave the counter clean for the next frame's binning */
+    if (threadIdx.x == 0) fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE] = 0;
 
     /* consecutive lanes take consecutive samples of a row: a wave stores whole 128-byte segments */
     for (uint32_t q = threadIdx.x; q < TILE_PIXELS * S; q += TILE_THREADS) {
@@ -1005,6 +1054,8 @@ __global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(Frame
 {
     __shared__ ShadeTables tb;
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
+    /* the frame's list counters were last read by the tile kernel: clear them for the next frame */
+    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
     stage_tables(tb, fp.tables);
     if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
     __syncthreads();
@@ -1097,18 +1148,14 @@ void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n
     hipLaunchKernelGGL(k_index_range, dim3(64, n_jobs), dim3(256), 0, s, jobs, out_max);
 }
 
-void launch_constants(const FrameParams& fp, hipStream_t s)
+void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s)
 {
-    uint32_t n = fp.tiles_x * fp.tiles_y;
-    if (fp.n_draws > n) n = fp.n_draws;
-    if (n < CTR_COUNT) n = CTR_COUNT;
-    hipLaunchKernelGGL(k_constants, dim3((n + 63) / 64), dim3(64), 0, s, fp);
-}
-
-void launch_vertex(const FrameParams& fp, hipStream_t s)
-{
-    if (!fp.n_vchunks) return;
-    hipLaunchKernelGGL(k_vertex, dim3((fp.n_vchunks + 3) / 4), dim3(256), 0, s, fp);
+    /* launched even without vertices when a uniform write is pending: it has to land */
+    const uint32_t blocks = (fp.n_vchunks + 3) / 4;
+    if (!blocks && !patch.dst) return;
+    VertexArgs args;
+    args.fp = fp; args.up = patch;
+    hipLaunchKernelGGL(k_vertex, dim3(blocks ? blocks : 1), dim3(256), 0, s, args);
 }
 
 void launch_setup(const FrameParams& fp, hipStream_t s)
