@@ -168,7 +168,7 @@ struct rnd_cmd_t {
     DeviceArray<TileEntry> d_tile_lists;
     DeviceArray<LargeEntry> d_large_list;
     DeviceArray<ClipTri> d_clip_tris;
-    DeviceArray<uint32_t> d_tile_count, d_clip_list, d_counters;
+    DeviceArray<uint32_t> d_tile_count, d_counters;
     FrameParams fp = {};
     uint32_t shard_index = 0, shard_count = 1;
 
@@ -176,7 +176,7 @@ struct rnd_cmd_t {
     {
         d_draws.release(); d_derived.release(); d_vchunks.release(); d_tchunks.release(); d_textures.release();
         d_svtx.release(); d_svary.release(); d_prim_rec.release(); d_tile_lists.release(); d_large_list.release(); d_clip_tris.release();
-        d_tile_count.release(); d_clip_list.release(); d_counters.release();
+        d_tile_count.release(); d_counters.release();
     }
 };
 
@@ -218,7 +218,7 @@ int report_overflow(rnd_device dev)
     const uint32_t ovf = *dev->status_host;
     memset(dev->status_host, 0, 64);
     return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, std::string("a work list overflowed while rendering (flags ") + std::to_string(ovf) +
-                "; pass-wide list=1, clip list=2, clipped triangles=4): the frame is incomplete");
+                "; pass-wide list=1, clipped triangles=4): the frame is incomplete");
 }
 
 bool format_is_srgb(int32_t f)
@@ -923,7 +923,6 @@ int rnd_cmd_end(rnd_cmd cmd)
     while (tile_cap > 256 && tile_cap * n_tiles * sizeof(TileEntry) > (size_t(2) << 30)) tile_cap >>= 1;
     while (tile_cap > 256 && tile_cap / 2 >= slots) tile_cap >>= 1;
     const size_t large_cap = 2 * slots + 65536;
-    const size_t clip_cap = slots ? slots : 1;
     const size_t clip_tri_cap = std::min<size_t>(MAX_FAN * slots, 2 * slots + 65536) + 1;
 
     cmd->release_compiled();
@@ -939,7 +938,6 @@ int rnd_cmd_end(rnd_cmd cmd)
     const size_t tile_stride = tile_cap + 16;
     HIP_TRY(cmd->d_tile_lists.resize(n_tiles * tile_stride));
     HIP_TRY(cmd->d_large_list.resize(large_cap));
-    HIP_TRY(cmd->d_clip_list.resize(clip_cap));
     HIP_TRY(cmd->d_clip_tris.resize(clip_tri_cap));
     HIP_TRY(cmd->d_counters.resize(CTR_COUNT));
     /* every frame leaves its counters at zero for the next one; the first frame needs them so */
@@ -952,10 +950,10 @@ int rnd_cmd_end(rnd_cmd cmd)
     fp.vchunks = cmd->d_vchunks.ptr; fp.tchunks = cmd->d_tchunks.ptr; fp.textures = cmd->d_textures.ptr;
     fp.svtx = cmd->d_svtx.ptr; fp.svary = cmd->d_svary.ptr; fp.prim_rec = cmd->d_prim_rec.ptr;
     fp.tile_count = cmd->d_tile_count.ptr; fp.tile_lists = cmd->d_tile_lists.ptr;
-    fp.large_list = cmd->d_large_list.ptr; fp.clip_list = cmd->d_clip_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
+    fp.large_list = cmd->d_large_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
     fp.counters = cmd->d_counters.ptr;
     fp.tile_capacity = (uint32_t)tile_cap; fp.tile_stride = (uint32_t)tile_stride; fp.large_capacity = (uint32_t)large_cap;
-    fp.clip_capacity = (uint32_t)clip_cap; fp.clip_tri_capacity = (uint32_t)clip_tri_cap;
+    fp.clip_tri_capacity = (uint32_t)clip_tri_cap;
     {
         void* dp = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&dp, dev->status_host, 0));
@@ -1027,14 +1025,11 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     { const char* dbg = getenv("RND_DEBUG"); fp.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u; }
     hipStream_t s = dev->stream;
     const bool prof = dev->profiling;
-    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CONSTANTS], s));
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_VERTEX], s));
     launch_vertex(fp, dev->pending, s);
     dev->pending.dst = nullptr;
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SETUP], s));
     launch_setup(fp, s);
-    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_CLIP], s));
-    launch_clip(fp, dev->status_host[1], s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_TILE], s));
     launch_tile(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SHADE], s));

@@ -253,18 +253,19 @@ __device__ __forceinline__ float plane_distance(int k, const ClipV& v)
     }
 }
 
-/* Polygon storage of the clipper: two buffers of up to 12 vertices x 7 floats per thread, kept in
- * LDS ([buffer][vertex][component][thread], so a wave's accesses are conflict free) instead of
- * per-thread arrays, which would become scratch memory. */
-constexpr int CLIP_THREADS = 64;
+/* Polygon storage of the clipper: two buffers of up to 12 vertices x 7 floats per clipping lane,
+ * kept in LDS ([buffer][vertex][component][lane], so the lanes' accesses are conflict free)
+ * instead of per-thread arrays, which would become scratch memory.  A wave clips CLIP_LANES
+ * primitives at a time. */
+constexpr int CLIP_LANES = 4;
 constexpr int CLIP_MAX_VERTS = 12;
-constexpr int CLIP_LDS_FLOATS = 2 * CLIP_MAX_VERTS * 7 * CLIP_THREADS;
+constexpr int CLIP_LDS_FLOATS = 2 * CLIP_MAX_VERTS * 7 * CLIP_LANES; /* per wave */
 
 struct ClipStore {
-    float* base; /* LDS array + this thread's index */
+    float* base; /* the wave's LDS block + this lane's index */
     __device__ __forceinline__ float* at(int buf, int i, int comp) const
     {
-        return base + ((buf * CLIP_MAX_VERTS + i) * 7 + comp) * CLIP_THREADS;
+        return base + ((buf * CLIP_MAX_VERTS + i) * 7 + comp) * CLIP_LANES;
     }
     __device__ __forceinline__ ClipV get(int buf, int i) const
     {

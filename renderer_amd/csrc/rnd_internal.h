@@ -17,8 +17,8 @@ constexpr int TILE_PIXELS = TILE_W * TILE_H;
 constexpr int TILE_THREADS = 256;
 constexpr int CHUNK = 64;            /* primitives (or vertices) handled by one wave */
 constexpr int MAX_TILES_PER_PRIM = 16; /* primitives touching more tiles go to the pass-wide list */
-enum : uint32_t { CTR_LARGE = 0, CTR_CLIP = 1, CTR_CLIP_TRIS = 2, CTR_OVERFLOW = 3, CTR_COUNT = 4 };
-enum : uint32_t { OVF_LARGE = 1, OVF_CLIP = 2, OVF_CLIP_TRIS = 4 };
+enum : uint32_t { CTR_LARGE = 0, CTR_CLIP_TRIS = 1, CTR_OVERFLOW = 2, CTR_COUNT = 3 };
+enum : uint32_t { OVF_LARGE = 1, OVF_CLIP_TRIS = 4 };
 constexpr int TILE_COUNT_STRIDE = 32; /* one tile counter per 128-byte line: atomics on neighbouring tiles do not share a line */
 constexpr int MAX_TILE_AXIS = 256;   /* tile coordinates are packed in 8 bits */
 constexpr int SUBPIXEL_BITS = 8;
@@ -168,11 +168,10 @@ struct FrameParams {
     uint32_t* tile_count;    /* tile t at [t*TILE_COUNT_STRIDE]: entries appended this frame (may exceed tile_capacity) */
     TileEntry* tile_lists;   /* tile t owns entries [t*tile_stride, t*tile_stride + tile_capacity) */
     LargeEntry* large_list;  /* primitives touching more than MAX_TILES_PER_PRIM tiles + tile-list overflow */
-    uint32_t* clip_list;     /* slots that need the clipper */
     ClipTri* clip_tris;
-    uint32_t* counters;      /* [0] large_list entries, [1] clip_list entries, [2] clip_tris used, [3] overflow flags */
+    uint32_t* counters;      /* [0] large_list entries, [1] clip_tris used, [2] overflow flags */
     uint32_t* status_host;   /* pinned host word: overflow flags of the last frame that had any */
-    uint32_t tile_capacity, large_capacity, clip_capacity, clip_tri_capacity;
+    uint32_t tile_capacity, large_capacity, clip_tri_capacity;
     uint32_t tile_stride;    /* capacity + 16 entries: lists do not all start on the same power-of-two boundary
                                 (equal low address bits would pile every tile onto the same memory channels) */
     uint8_t* color;          /* resolved colour, width*height*4 */
@@ -202,7 +201,6 @@ struct FrameParams {
 void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n_jobs, hipStream_t s);
 void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s);
 void launch_setup(const FrameParams& fp, hipStream_t s);
-void launch_clip(const FrameParams& fp, uint32_t expected, hipStream_t s);
 void launch_tile(const FrameParams& fp, hipStream_t s);
 void launch_shade(const FrameParams& fp, hipStream_t s);
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,

@@ -350,8 +350,51 @@ __device__ __forceinline__ void bin_one(const FrameParams& fp, const TileEntry& 
     }
 }
 
-__global__ __launch_bounds__(256) void k_setup(FrameParams fp)
+/* Clips one primitive against near, far and the guard band, writes its fan of triangles and
+ * bins them.  One lane per primitive. */
+__device__ __forceinline__ void clip_primitive(const FrameParams& fp, const DrawStatic& d, uint32_t draw, uint32_t slot,
+                                               uint32_t i0, uint32_t i1, uint32_t i2, const ClipStore& st)
 {
+    int buf = 0;
+    const int corners = build_clip_fan(d, fp.derived[draw].clip_m, i0, i1, i2, st, buf);
+    if (corners < 3) return;
+    const uint32_t count = (uint32_t)corners - 2u;
+    const uint32_t first = atomicAdd(&fp.counters[CTR_CLIP_TRIS], count);
+    if (first + count > fp.clip_tri_capacity) { flag_overflow(fp, OVF_CLIP_TRIS); return; }
+    PrimRec pr = {first, 0u, 0u, draw | FLAG_CLIPPED};
+    fp.prim_rec[slot] = pr;
+#pragma unroll 1
+    for (int k = 1; k + 1 < corners; ++k) {
+        RTri t; float bary[3][3];
+        ClipTri ct;
+        const bool ok = fan_triangle(fp, st, buf, k, d.cull_mode, d.front_face, t, bary);
+        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+        const bool vis = ok && pixel_box(fp, t, x0, y0, x1, y1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            ct.x[q] = t.x[q]; ct.y[q] = t.y[q]; ct.z[q] = t.z[q]; ct.iw[q] = t.iw[q];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ct.bary[q * 3 + j] = ok ? bary[q][j] : 0.0f;
+        }
+        ct.v[0] = d.svtx_base + i0; ct.v[1] = d.svtx_base + i1; ct.v[2] = d.svtx_base + i2;
+        ct.draw = draw;
+        ct.valid = vis ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) ct.pad[j] = 0;
+        const uint32_t idx = first + (uint32_t)(k - 1);
+        fp.clip_tris[idx] = ct;
+        if (vis) {
+            TileEntry e = {idx, 0u, 0u, slot | ((uint32_t)(k - 1) << ENTRY_SUB_SHIFT) | FLAG_CLIPPED};
+            bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, y0 >> TILE_SHIFT, x1 >> TILE_SHIFT, y1 >> TILE_SHIFT));
+        }
+    }
+}
+
+/* One wave per chunk of 64 primitives of one draw: fetch, classify, cull and orient, bin; then
+ * clip the few that need it. */
+__global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
+{
+    __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_tchunks) return;
     const Chunk c = fp.tchunks[chunk];
@@ -363,6 +406,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp)
     TileEntry e = {0, 0, 0, slot};
     uint32_t box = BBOX_CULLED;
     PrimFetch pf;
+    pf.idx[0] = pf.idx[1] = pf.idx[2] = 0;
     if (tri < d.tri_count && fetch_prim(fp, d, tri, pf)) {
         const int cls = (fp.debug_flags & 4u) ? 0 : classify_prim(pf);
         if (fp.debug_flags & 4u) { if (pf.oc_any == 0xFFFFu) fp.prim_rec[slot].v0 = 1; }
@@ -386,71 +430,26 @@ __global__ __launch_bounds__(256) void k_setup(FrameParams fp)
             }
         }
     }
-    /* primitives for the clipper: one atomic per wave, slots stored in lane order */
-    const uint64_t cm = __ballot(needs_clip);
-    if (cm) {
-        const int leader = __ffsll((unsigned long long)cm) - 1;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&fp.counters[CTR_CLIP], (uint32_t)__popcll(cm));
-        base = (uint32_t)__shfl((int)base, leader);
-        if (needs_clip) {
-            const uint32_t pos = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-            if (pos < fp.clip_capacity) fp.clip_list[pos] = slot;
-            else flag_overflow(fp, OVF_CLIP);
-        }
-    }
     if (!(fp.debug_flags & 8u)) bin_wave(fp, valid, e, box);
-}
 
-/* ------------------------------------------------------------------ clipper: one lane per primitive that crosses
- * the near plane, the far plane or the guard band.  Kept out of the setup and tile kernels so
- * those carry no scratch memory. */
-
-__global__ __launch_bounds__(CLIP_THREADS) void k_clip(FrameParams fp)
-{
-    __shared__ float lds_poly[CLIP_LDS_FLOATS];
+    /* Primitives that cross the near plane, the far plane or the guard band (rare): the wave clips
+     * them CLIP_LANES at a time, lane j taking the j-th of them, with the polygons in LDS. */
+    uint64_t cm = __ballot(needs_clip);
+    if (!cm) return;
     ClipStore st;
-    st.base = lds_poly + threadIdx.x;
-    const uint32_t n = min(fp.counters[CTR_CLIP], fp.clip_capacity);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = fp.clip_list[i];
-        uint32_t draw, tri;
-        slot_to_prim(fp, slot, draw, tri);
-        const DrawStatic& d = fp.draws[draw];
-        const uint32_t* ip = d.ib + (size_t)tri * 3;
-        const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
-        int buf = 0;
-        const int corners = build_clip_fan(d, fp.derived[draw].clip_m, i0, i1, i2, st, buf);
-        if (corners < 3) continue;
-        const uint32_t count = (uint32_t)corners - 2u;
-        const uint32_t first = atomicAdd(&fp.counters[CTR_CLIP_TRIS], count);
-        if (first + count > fp.clip_tri_capacity) { flag_overflow(fp, OVF_CLIP_TRIS); continue; }
-        PrimRec pr = {first, 0u, 0u, draw | FLAG_CLIPPED};
-        fp.prim_rec[slot] = pr;
-        for (int k = 1; k + 1 < corners; ++k) {
-            RTri t; float bary[3][3];
-            ClipTri ct;
-            const bool ok = fan_triangle(fp, st, buf, k, d.cull_mode, d.front_face, t, bary);
-            int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-            const bool vis = ok && pixel_box(fp, t, x0, y0, x1, y1);
+    st.base = clip_lds[threadIdx.x >> 6] + (lane & (CLIP_LANES - 1));
+    while (cm) {
+        int src = -1;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                ct.x[q] = t.x[q]; ct.y[q] = t.y[q]; ct.z[q] = t.z[q]; ct.iw[q] = t.iw[q];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) ct.bary[q * 3 + j] = ok ? bary[q][j] : 0.0f;
-            }
-            ct.v[0] = d.svtx_base + i0; ct.v[1] = d.svtx_base + i1; ct.v[2] = d.svtx_base + i2;
-            ct.draw = draw;
-            ct.valid = vis ? 1u : 0u;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) ct.pad[j] = 0;
-            const uint32_t idx = first + (uint32_t)(k - 1);
-            fp.clip_tris[idx] = ct;
-            if (vis) {
-                TileEntry e = {idx, 0u, 0u, slot | ((uint32_t)(k - 1) << ENTRY_SUB_SHIFT) | FLAG_CLIPPED};
-                bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, y0 >> TILE_SHIFT, x1 >> TILE_SHIFT, y1 >> TILE_SHIFT));
-            }
+        for (int j = 0; j < CLIP_LANES; ++j) {
+            const int l = cm ? __ffsll((unsigned long long)cm) - 1 : -1;
+            if ((int)lane == j) src = l;
+            cm &= cm - 1ull; /* no-op once empty */
         }
+        const int from = src < 0 ? (int)lane : src;
+        const uint32_t i0 = (uint32_t)__shfl((int)pf.idx[0], from), i1 = (uint32_t)__shfl((int)pf.idx[1], from),
+                       i2 = (uint32_t)__shfl((int)pf.idx[2], from);
+        if (src >= 0 && lane < (uint32_t)CLIP_LANES) clip_primitive(fp, d, c.draw, chunk * 64u + (uint32_t)src, i0, i1, i2, st);
     }
 }
 
@@ -1021,7 +1020,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t ovf = fp.counters[CTR_OVERFLOW];
         if (ovf) fp.status_host[0] = ovf; /* a list overflowed: the host reports it at the next wait */
-        fp.status_host[1] = fp.counters[CTR_CLIP]; /* sizes the next frame's clip launch */
     }
     __syncthreads();
     /* every thread has read the list length: leave the counter clean for the next frame's binning */
@@ -1162,16 +1160,6 @@ void launch_setup(const FrameParams& fp, hipStream_t s)
 {
     if (!fp.n_tchunks) return;
     hipLaunchKernelGGL(k_setup, dim3((fp.n_tchunks + 3) / 4), dim3(256), 0, s, fp);
-}
-
-void launch_clip(const FrameParams& fp, uint32_t expected, hipStream_t s)
-{
-    if (!fp.n_tchunks) return;
-    /* grid-stride kernel: any grid is correct; size it for the count the previous frame saw */
-    uint32_t blocks = (expected + expected / 4 + 63) / 64;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(CLIP_THREADS), 0, s, fp);
 }
 
 void launch_tile(const FrameParams& fp, hipStream_t s)
