@@ -78,6 +78,22 @@ def cpu_baseline(scene, budget_s=12.0):
                 frames, scene.name, scene.width, scene.height, scene.triangle_count(), el)}
 
 
+def measured_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed counter pass of this workload
+    (profiles/traffic.json, written by tools/summarize_profiles.py from rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command), or None when there is none."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f).get("config%d" % config, {})
+    except (OSError, ValueError):
+        return None
+    for name, row in table.items():
+        if name.split("<")[0] == kernel:
+            return int(row["read_bytes"] + row["write_bytes"])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,14 +186,19 @@ def main():
                 acc[k] = acc.get(k, 0.0) + v
         run.dev.set_profiling(False)
         stages = {k: v / max(args.profile_steps, 1) for k, v in acc.items()}
+        # Roofline of the longest kernel: the part of the frame's algorithmic bytes that kernel
+        # moves (scenes.Scene.algorithmic_bytes_by_stage) over its own duration.  The event pair
+        # around a kernel also spans the event records themselves, a few microseconds; the
+        # rocprofv3 averages under profiles/ are the durations without that.
         dom = max(stages, key=stages.get)
-        bytes_frame = scene.algorithmic_bytes()
+        share = scene.algorithmic_bytes_by_stage()[dom]
         if tiles_mode:
-            bytes_frame = bytes_frame / world
-        achieved = bytes_frame / (stages[dom] * 1e-3) / 1e9
+            share = share / world
+        achieved = share / (stages[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "algorithmic_bytes_per_launch": bytes_frame,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": measured_traffic("k_" + dom, args.config),
+                    "algorithmic_bytes_per_launch": share,
                     "kernel_ms": round(stages[dom], 5)}
 
     cpu = None
@@ -196,6 +217,7 @@ def main():
                 scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws)),
                 "sharding": ("tiles of one frame over %d GPUs + RCCL all_gather" % world) if tiles_mode
                 else ("one view per GPU, %d GPUs" % world), "seed": scene.seed},
+            "frame_algorithmic_bytes": scene.algorithmic_bytes(),
             "frame_hbm_frac": round(scene.algorithmic_bytes() * frames_total / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "stage_ms": {k: round(v, 5) for k, v in stages.items()},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -70,10 +70,11 @@ class Scene:
     def triangle_count(self):
         return sum(d["index_count"] // 3 for d in self.draws)
 
-    def algorithmic_bytes(self):
-        """Bytes a frame must move at the least: every distinct vertex and index once,
-        one 80-byte constant record per draw, colour and depth stored once, and one
-        texel per pixel (or the whole texture if smaller)."""
+    def algorithmic_bytes_by_stage(self):
+        """Bytes a frame must move at the least, split by the kernel that moves them: every
+        distinct vertex once (vertex), every index once plus one 80-byte constant record per
+        draw (setup), the depth image stored once (tile), the colour image stored once plus one
+        texel per pixel, or the whole texture if smaller (shade)."""
         vb = sum(int(v.nbytes) for v in self.vbs)
         ib = sum(int(i.nbytes) for i in self.ibs)
         px = self.width * self.height * 4
@@ -84,7 +85,11 @@ class Scene:
                 h, w = t["texels"].shape[:2]
                 tb += int(w * h * 4 * 4 / 3) if t.get("gen_mips", True) else w * h * 4
             tex = min(px, tb)
-        return vb + ib + 80 * len(self.draws) + px + px + tex
+        return {"vertex": vb, "setup": ib + 80 * len(self.draws), "tile": px, "shade": px + tex}
+
+    def algorithmic_bytes(self):
+        """Sum of algorithmic_bytes_by_stage(): the least a whole frame moves."""
+        return sum(self.algorithmic_bytes_by_stage().values())
 
 
 def default_pipeline(shader, samples=1, **kw):

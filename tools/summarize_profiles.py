@@ -2,7 +2,9 @@
 """Folds the rocprofv3 CSVs written by tools/collect_profiles.sh into one table per round:
 average duration per kernel (kernel trace) and average counter values per kernel launch (PMC).
 
-    python tools/summarize_profiles.py gpurun_out/prof_r01 profiles/r01
+    python tools/summarize_profiles.py gpurun_out/prof_r01 profiles/r01 [CONFIG]
+
+With CONFIG the per-kernel HBM traffic also goes into profiles/traffic.json, which bench.py reads.
 """
 import collections
 import csv
@@ -17,7 +19,7 @@ def find(d, suffix):
     return hits[0] if hits else None
 
 
-def main(src, dst_prefix):
+def main(src, dst_prefix, config=None):
     rows = {}
     stats = find(os.path.join(src, "trace"), "kernel_stats.csv")
     if stats:
@@ -62,7 +64,18 @@ def main(src, dst_prefix):
     with open(dst_prefix + "_traffic.json", "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     print("wrote", dst_prefix + "_pmc.csv", dst_prefix + "_traffic.json")
+    if config is not None:
+        # the table bench.py reads for roofline.traffic: one entry per benchmark configuration
+        path = os.path.join(os.path.dirname(dst_prefix) or ".", "traffic.json")
+        try:
+            table = json.load(open(path))
+        except (OSError, ValueError):
+            table = {}
+        table["config%d" % config] = {k: v for k, v in traffic.items() if k.startswith("k_")}
+        with open(path, "w") as f:
+            json.dump(table, f, indent=1, sort_keys=True)
+        print("updated", path)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else None)
