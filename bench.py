@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--mode", choices=["views", "tiles"], default="views")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="command buffers / targets the frames rotate through (the reference's swapchain image count)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=20)
     args = ap.parse_args()
@@ -119,8 +121,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     scene = build_scene(args.config)
-    run = SceneRunner(scene, ordinal=local_rank)
     tiles_mode = args.mode == "tiles" and world > 1
+    # the tiles mode gathers every frame before the next starts: one image is all it can use
+    run = SceneRunner(scene, ordinal=local_rank, frames_in_flight=1 if tiles_mode else args.frames_in_flight)
     if tiles_mode:
         run.cmd.set_tile_shard(rank, world)
 
@@ -216,7 +219,8 @@ def main():
             "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, 1 sample/pixel" % (
                 scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws)),
                 "sharding": ("tiles of one frame over %d GPUs + RCCL all_gather" % world) if tiles_mode
-                else ("one view per GPU, %d GPUs" % world), "seed": scene.seed},
+                else ("one view per GPU, %d GPUs" % world), "frames_in_flight": run.frames_in_flight,
+                "seed": scene.seed},
             "frame_algorithmic_bytes": scene.algorithmic_bytes(),
             "frame_hbm_frac": round(scene.algorithmic_bytes() * frames_total / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "stage_ms": {k: round(v, 5) for k, v in stages.items()},

@@ -16,6 +16,7 @@
 #include <map>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 using namespace rnd;
@@ -76,9 +77,22 @@ struct rnd_device_t {
     bool stage_used[STAGE_SLOTS] = {};
     int stage_next = 0;
     uint32_t* status_host = nullptr; /* pinned word the tile kernel writes when a work list overflowed */
-    /* the latest small write to a uniform buffer, held back until the next submit carries it in
-     * its kernel arguments (or until something else needs the buffer's bytes in memory) */
+    /* The latest small write to a uniform buffer.  It never goes to memory by itself: every
+     * submit from then on carries it in its kernel arguments and the vertex kernel reads the
+     * buffer through it, so frames in flight each see the bytes that were current at their
+     * submit and nothing on the GPU writes uniform memory.  It is stored to memory (flush_pending)
+     * only when something else needs the buffer's bytes there. */
     UniformPatch pending = {};
+    /* Frames in flight: every command buffer of a device that owns its stream executes on a
+     * stream of its own, so consecutive frames overlap on the GPU like the reference's frames
+     * in flight (vk_app.cpp:109-130).  What stays ordered across those streams:
+     *  - work queued on the device's own stream (uploads, copies) precedes later frames (order_ev)
+     *    and follows the frames already submitted (their done events);
+     *  - frames that render into the same target run one after the other (the target's event). */
+    std::vector<rnd_cmd> cmds;
+    std::vector<rnd_target> targets;
+    hipEvent_t order_ev = nullptr;
+    bool stream_dirty = false;
     bool profiling = false;
     hipEvent_t ev[RND_STAGE_COUNT + 1] = {};
     float stage_ms[RND_STAGE_COUNT] = {};
@@ -107,6 +121,9 @@ struct rnd_target_t {
     uint8_t* color;
     uint32_t* depth;
     uint32_t* vis; /* owning primitive per sample, handed from the tile kernel to the shading kernel */
+    hipEvent_t order_ev;       /* recorded on last_stream when another stream has to wait for it */
+    hipStream_t last_stream;   /* stream of the last frame rendered into, or copy taken from, this target */
+    bool last_valid;
 };
 
 struct rnd_pipeline_t {
@@ -139,6 +156,10 @@ enum CmdState { CMD_INITIAL, CMD_RECORDING, CMD_IN_PASS, CMD_EXECUTABLE };
 
 struct rnd_cmd_t {
     rnd_device dev = nullptr;
+    hipStream_t stream = nullptr; /* the device's stream, or this command buffer's own */
+    bool own_stream = false;
+    hipEvent_t done_ev = nullptr; /* recorded on the stream's tail when another stream has to wait for it */
+    bool submitted = false;       /* work may still be running on the stream */
     CmdState state = CMD_INITIAL;
     /* pass */
     bool has_pass = false;
@@ -188,7 +209,40 @@ int set_device(rnd_device dev)
     return RND_SUCCESS;
 }
 
-/* after the stream has been waited for: did a frame overflow one of its work lists? */
+/* waits for everything queued on the device: its own stream and every command buffer's */
+hipError_t sync_all(rnd_device dev)
+{
+    hipError_t e = hipStreamSynchronize(dev->stream);
+    for (rnd_cmd c : dev->cmds) {
+        if (!c->own_stream) continue;
+        const hipError_t e2 = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    dev->stream_dirty = false;
+    for (rnd_cmd c : dev->cmds) c->submitted = false;
+    return e;
+}
+
+/* Cross-stream order is set up where it is needed, not on every submit: the producer's tail is
+ * marked with an event at that moment and the waiter waits for it. */
+hipError_t wait_for_stream(hipStream_t waiter, hipStream_t producer, hipEvent_t ev)
+{
+    if (waiter == producer) return hipSuccess;
+    const hipError_t e = hipEventRecord(ev, producer);
+    return e != hipSuccess ? e : hipStreamWaitEvent(waiter, ev, 0);
+}
+
+/* the device's stream waits for every frame already submitted */
+hipError_t follow_frames(rnd_device dev)
+{
+    for (rnd_cmd c : dev->cmds) {
+        if (!c->own_stream || !c->submitted) continue;
+        const hipError_t e = wait_for_stream(dev->stream, c->stream, c->done_ev);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 /* stream-ordered small upload through the pinned ring: returns without waiting for the device */
 int staged_write(rnd_device dev, uint8_t* dst, const void* src, size_t bytes)
 {
@@ -197,9 +251,12 @@ int staged_write(rnd_device dev, uint8_t* dst, const void* src, size_t bytes)
     if (dev->stage_used[slot]) HIP_TRY(hipEventSynchronize(dev->stage_ev[slot]));
     uint8_t* staging = dev->stage_host + (size_t)slot * rnd_device_t::STAGE_SLOT_BYTES;
     memcpy(staging, src, bytes);
+    /* frames already queued read the old bytes: the copy follows them */
+    HIP_TRY(follow_frames(dev));
     HIP_TRY(hipMemcpyAsync(dst, staging, bytes, hipMemcpyHostToDevice, dev->stream));
     HIP_TRY(hipEventRecord(dev->stage_ev[slot], dev->stream));
     dev->stage_used[slot] = true;
+    dev->stream_dirty = true;
     return RND_SUCCESS;
 }
 
@@ -341,6 +398,7 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&dev->stage_ev[i], hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->status_host), 64, hipHostMallocDefault));
     memset(dev->status_host, 0, 64);
+    HIP_TRY(hipEventCreateWithFlags(&dev->order_ev, hipEventDisableTiming));
     *out = dev;
     return RND_SUCCESS;
 }
@@ -349,7 +407,8 @@ int rnd_device_destroy(rnd_device dev)
 {
     if (!dev) return RND_SUCCESS;
     (void)hipSetDevice(dev->ordinal);
-    (void)hipStreamSynchronize(dev->stream);
+    (void)sync_all(dev);
+    if (dev->order_ev) (void)hipEventDestroy(dev->order_ev);
     if (dev->tables) (void)hipFree(dev->tables);
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) if (dev->ev[i]) (void)hipEventDestroy(dev->ev[i]);
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) if (dev->stage_ev[i]) (void)hipEventDestroy(dev->stage_ev[i]);
@@ -364,7 +423,7 @@ int rnd_device_wait_idle(rnd_device dev)
 {
     if (!dev) return fail(RND_ERROR_INVALID_ARGUMENT, "device is null");
     if (int r = set_device(dev)) return r;
-    HIP_TRY(hipStreamSynchronize(dev->stream));
+    HIP_TRY(sync_all(dev));
     return report_overflow(dev);
 }
 
@@ -414,7 +473,7 @@ int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t 
     /* stream-ordered after earlier submits: a frame already queued still sees the old bytes */
     if ((buf->usage & RND_BUFFER_USAGE_UNIFORM) && bytes <= PATCH_MAX_BYTES && bytes % 4 == 0 && offset % 4 == 0) {
         /* the per-frame uniform block (base_obj_viewer_app.cpp:134-138): no copy is queued; the
-         * next submit takes the bytes along in its kernel arguments */
+         * submits that follow take the bytes along in their kernel arguments */
         uint8_t* dst = buf->ptr + offset;
         if (dev->pending.dst && !(dev->pending.dst == dst && dev->pending.bytes == (uint32_t)bytes))
             if (int r = flush_pending(dev)) return r;
@@ -425,6 +484,8 @@ int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t 
     }
     if (int r = flush_pending(dev)) return r;
     if (bytes <= rnd_device_t::STAGE_SLOT_BYTES) return staged_write(dev, buf->ptr + offset, src, (size_t)bytes);
+    /* a large upload (geometry): frames in flight may still read the buffer, wait them out */
+    HIP_TRY(sync_all(dev));
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, src, (size_t)bytes, hipMemcpyHostToDevice, dev->stream));
     HIP_TRY(hipStreamSynchronize(dev->stream));
     return RND_SUCCESS;
@@ -436,7 +497,10 @@ int rnd_buffer_write_device(rnd_buffer buf, uint64_t offset, const void* device_
     if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write_device: range outside the buffer");
     if (int r = set_device(buf->dev)) return r;
     if (int r = flush_pending(buf->dev)) return r;
+    /* queued on the device's stream behind every frame already submitted; later frames follow it */
+    HIP_TRY(follow_frames(buf->dev));
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, device_src, (size_t)bytes, hipMemcpyDeviceToDevice, buf->dev->stream));
+    buf->dev->stream_dirty = true;
     return RND_SUCCESS;
 }
 
@@ -446,7 +510,7 @@ int rnd_buffer_read(rnd_buffer buf, uint64_t offset, void* dst, uint64_t bytes)
     if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_read: range outside the buffer");
     if (int r = set_device(buf->dev)) return r;
     if (int r = flush_pending(buf->dev)) return r;
-    HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+    HIP_TRY(sync_all(buf->dev));
     HIP_TRY(hipMemcpy(dst, buf->ptr + offset, (size_t)bytes, hipMemcpyDeviceToHost));
     return RND_SUCCESS;
 }
@@ -457,7 +521,7 @@ int rnd_buffer_destroy(rnd_buffer buf)
     (void)hipSetDevice(buf->dev->ordinal);
     /* a held-back write into this buffer has nowhere to go any more */
     if (buf->dev->pending.dst >= buf->ptr && buf->dev->pending.dst < buf->ptr + buf->bytes) buf->dev->pending.dst = nullptr;
-    (void)hipStreamSynchronize(buf->dev->stream);
+    (void)sync_all(buf->dev);
     (void)hipFree(buf->ptr);
     delete buf;
     return RND_SUCCESS;
@@ -528,7 +592,7 @@ int rnd_texture_read_level(rnd_texture tex, uint32_t level, void* rgba8_out)
 {
     if (!tex || !rgba8_out || level >= tex->levels) return fail(RND_ERROR_INVALID_ARGUMENT, "texture_read_level: bad arguments");
     if (int r = set_device(tex->dev)) return r;
-    HIP_TRY(hipStreamSynchronize(tex->dev->stream));
+    HIP_TRY(sync_all(tex->dev));
     HIP_TRY(hipMemcpy(rgba8_out, tex->level_ptr[level], (size_t)level_dim(tex->width, level) * level_dim(tex->height, level) * 4,
                       hipMemcpyDeviceToHost));
     return RND_SUCCESS;
@@ -538,7 +602,7 @@ int rnd_texture_destroy(rnd_texture tex)
 {
     if (!tex) return RND_SUCCESS;
     (void)hipSetDevice(tex->dev->ordinal);
-    (void)hipStreamSynchronize(tex->dev->stream);
+    (void)sync_all(tex->dev);
     for (uint32_t l = 0; l < 16; ++l) if (tex->level_ptr[l]) (void)hipFree(tex->level_ptr[l]);
     delete tex;
     return RND_SUCCESS;
@@ -558,7 +622,8 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
     if (depth_format != RND_FORMAT_D24_UNORM_S8_UINT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "depth format must be D24_UNORM_S8_UINT");
     if (samples != 1 && samples != 4) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "sample count must be 1 or 4");
     if (int r = set_device(dev)) return r;
-    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, nullptr};
+    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    if (hipEventCreateWithFlags(&t->order_ev, hipEventDisableTiming) != hipSuccess) { delete t; return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed"); }
     size_t px = (size_t)width * height;
     hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&t->color), px * 4);
     hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&t->depth), px * samples * 4);
@@ -566,6 +631,7 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
     if (e1 != hipSuccess || e2 != hipSuccess) { rnd_target_destroy(t); return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc target failed"); }
     (void)hipMemset(t->color, 0, px * 4);
     (void)hipMemset(t->depth, 0, px * samples * 4);
+    dev->targets.push_back(t);
     *out = t;
     return RND_SUCCESS;
 }
@@ -574,7 +640,7 @@ int rnd_target_read(rnd_target target, void* color_out, uint32_t* depth_out)
 {
     if (!target) return fail(RND_ERROR_INVALID_ARGUMENT, "target_read: target is null");
     if (int r = set_device(target->dev)) return r;
-    HIP_TRY(hipStreamSynchronize(target->dev->stream));
+    HIP_TRY(sync_all(target->dev));
     size_t px = (size_t)target->width * target->height;
     if (color_out) HIP_TRY(hipMemcpy(color_out, target->color, px * 4, hipMemcpyDeviceToHost));
     if (depth_out) HIP_TRY(hipMemcpy(depth_out, target->depth, px * target->samples * 4, hipMemcpyDeviceToHost));
@@ -587,7 +653,12 @@ int rnd_target_copy_color(rnd_target target, void* device_dst)
 {
     if (!target || !device_dst) return fail(RND_ERROR_INVALID_ARGUMENT, "target_copy_color: bad arguments");
     if (int r = set_device(target->dev)) return r;
-    HIP_TRY(hipMemcpyAsync(device_dst, target->color, (size_t)target->width * target->height * 4, hipMemcpyDeviceToDevice, target->dev->stream));
+    /* queued behind the frame that last rendered into the target, on that frame's stream; a
+     * later frame into the target follows the copy */
+    hipStream_t s = target->last_valid ? target->last_stream : target->dev->stream;
+    HIP_TRY(hipMemcpyAsync(device_dst, target->color, (size_t)target->width * target->height * 4, hipMemcpyDeviceToDevice, s));
+    target->last_stream = s; target->last_valid = true;
+    if (s == target->dev->stream) target->dev->stream_dirty = true;
     return RND_SUCCESS;
 }
 
@@ -595,7 +666,9 @@ int rnd_target_destroy(rnd_target target)
 {
     if (!target) return RND_SUCCESS;
     (void)hipSetDevice(target->dev->ordinal);
-    (void)hipStreamSynchronize(target->dev->stream);
+    (void)sync_all(target->dev);
+    if (target->order_ev) (void)hipEventDestroy(target->order_ev);
+    { auto& list = target->dev->targets; list.erase(std::remove(list.begin(), list.end(), target), list.end()); }
     if (target->color) (void)hipFree(target->color);
     if (target->depth) (void)hipFree(target->depth);
     if (target->vis) (void)hipFree(target->vis);
@@ -642,8 +715,22 @@ int rnd_pipeline_destroy(rnd_pipeline p)
 int rnd_cmd_create(rnd_device dev, rnd_cmd* out)
 {
     if (!dev || !out) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd_create: bad arguments");
+    if (int r = set_device(dev)) return r;
     rnd_cmd c = new rnd_cmd_t();
     c->dev = dev;
+    c->stream = dev->stream;
+    if (dev->own_stream) {
+        /* a caller-supplied stream keeps everything on that stream; otherwise frames of different
+         * command buffers may overlap, each on its own stream */
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(RND_ERROR_DEVICE_LOST, "hipStreamCreate failed"); }
+        c->own_stream = true;
+    }
+    if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed");
+    }
+    dev->cmds.push_back(c);
     *out = c;
     return RND_SUCCESS;
 }
@@ -653,7 +740,7 @@ int rnd_cmd_begin(rnd_cmd cmd)
     if (!cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd is null");
     if (cmd->state == CMD_RECORDING || cmd->state == CMD_IN_PASS) return fail(RND_ERROR_RECORDING, "command buffer is already recording");
     if (int r = set_device(cmd->dev)) return r;
-    (void)hipStreamSynchronize(cmd->dev->stream);
+    (void)sync_all(cmd->dev);
     cmd->release_compiled();
     cmd->draws.clear();
     cmd->has_pass = false; cmd->has_viewport = false; cmd->has_scissor = false;
@@ -1006,8 +1093,15 @@ int rnd_cmd_destroy(rnd_cmd cmd)
 {
     if (!cmd) return RND_SUCCESS;
     (void)hipSetDevice(cmd->dev->ordinal);
-    (void)hipStreamSynchronize(cmd->dev->stream);
+    (void)sync_all(cmd->dev);
+    if (cmd->own_stream)
+        for (rnd_target t : cmd->dev->targets)
+            if (t->last_stream == cmd->stream) t->last_valid = false; /* all finished; the stream goes away */
     cmd->release_compiled();
+    auto& list = cmd->dev->cmds;
+    list.erase(std::remove(list.begin(), list.end(), cmd), list.end());
+    if (cmd->done_ev) (void)hipEventDestroy(cmd->done_ev);
+    if (cmd->own_stream) (void)hipStreamDestroy(cmd->stream);
     delete cmd;
     return RND_SUCCESS;
 }
@@ -1023,11 +1117,18 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     FrameParams fp = cmd->fp;
     fp.shard_index = cmd->shard_index; fp.shard_count = cmd->shard_count;
     { const char* dbg = getenv("RND_DEBUG"); fp.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u; }
-    hipStream_t s = dev->stream;
+    hipStream_t s = cmd->stream;
+    rnd_target tg = cmd->target;
+    if (s != dev->stream && dev->stream_dirty) {
+        /* uploads and copies queued on the device's stream come first */
+        HIP_TRY(hipEventRecord(dev->order_ev, dev->stream));
+        HIP_TRY(hipStreamWaitEvent(s, dev->order_ev, 0));
+        dev->stream_dirty = false;
+    }
+    if (tg && tg->last_valid) HIP_TRY(wait_for_stream(s, tg->last_stream, tg->order_ev));
     const bool prof = dev->profiling;
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_VERTEX], s));
-    launch_vertex(fp, dev->pending, s);
-    dev->pending.dst = nullptr;
+    launch_vertex(fp, dev->pending, s); /* the pending uniform write stays pending: later frames carry it too */
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SETUP], s));
     launch_setup(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_TILE], s));
@@ -1036,6 +1137,10 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     launch_shade(fp, s);
     if (prof) { HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_COUNT], s)); dev->stage_valid = true; }
     HIP_TRY(hipGetLastError());
+    if (cmd->own_stream) {
+        cmd->submitted = true;
+        if (tg) { tg->last_stream = s; tg->last_valid = true; }
+    }
     if (fence) {
         HIP_TRY(hipEventRecord(fence->ev, s));
         fence->pending = true;

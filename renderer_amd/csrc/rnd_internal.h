@@ -127,9 +127,9 @@ struct DrawDerived {
     float clip_m[16];
 };
 
-/* A small host write to a uniform buffer that has not reached device memory yet.  It rides in
- * the arguments of the next frame's first kernel, which reads the buffer through it and also
- * stores it, so the per-frame 320-byte update costs no copy of its own. */
+/* A small host write to a uniform buffer that has not reached device memory.  It rides in the
+ * arguments of every frame's first kernel, which reads the buffer through it, so the per-frame
+ * 320-byte update costs no copy and frames in flight each keep their own bytes. */
 constexpr uint32_t PATCH_MAX_BYTES = 512;
 struct UniformPatch {
     uint8_t* dst;       /* device address the bytes belong at (4-byte aligned), or null */

@@ -196,16 +196,11 @@ __device__ __forceinline__ void wave_matrices(const UniformPatch& up, const Draw
     }
 }
 
-/* One wave per chunk of 64 vertices of one draw.  First kernel of a frame: workgroup 0 also lands
- * the pending uniform write in memory. */
+/* One wave per chunk of 64 vertices of one draw. */
 __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 {
     const FrameParams& fp = args.fp;
     const UniformPatch& up = args.up;
-    if (blockIdx.x == 0 && up.dst) {
-        for (uint32_t i = threadIdx.x; i < up.bytes / 4u; i += blockDim.x)
-            reinterpret_cast<uint32_t*>(up.dst)[i] = __float_as_uint(uniform_read(up, reinterpret_cast<const float*>(up.dst) + i));
-    }
     uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_vchunks) return;
     const Chunk c = fp.vchunks[chunk];
@@ -1148,12 +1143,11 @@ void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n
 
 void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s)
 {
-    /* launched even without vertices when a uniform write is pending: it has to land */
     const uint32_t blocks = (fp.n_vchunks + 3) / 4;
-    if (!blocks && !patch.dst) return;
+    if (!blocks) return;
     VertexArgs args;
     args.fp = fp; args.up = patch;
-    hipLaunchKernelGGL(k_vertex, dim3(blocks ? blocks : 1), dim3(256), 0, s, args);
+    hipLaunchKernelGGL(k_vertex, dim3(blocks), dim3(256), 0, s, args);
 }
 
 void launch_setup(const FrameParams& fp, hipStream_t s)

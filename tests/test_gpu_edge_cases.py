@@ -236,6 +236,55 @@ def test_uniforms_are_read_at_execution(device, oracle):
     assert np.array_equal(d2, od) and np.array_equal(c2, oc)
 
 
+@pytest.mark.parametrize("images", [2, 3])
+def test_frames_in_flight_keep_their_uniforms(device, oracle, images):
+    """Frames rotate through `images` command buffers and targets without the host waiting
+    (vk_app.cpp:109-130: one fence per frame in flight).  Each frame must be drawn with the
+    uniform block written just before its submit, whatever overlaps on the GPU."""
+    sc = scenes.config0(320, 180, tex_size=64, segments=48, rings=24)
+    model = np.asarray(sc.ubos[0][48:64], dtype=np.float32).reshape(4, 4)
+    n_frames = 3 * images + 1
+    ubos = []
+    for i in range(n_frames):
+        cam = hm.Camera()
+        cam.eye_position = np.array([0.25 * np.sin(0.9 * i), 0.1 * i, -2.0 - 0.05 * i], dtype=np.float32)
+        ubos.append(hm.global_ubo(cam, model, sc.width, sc.height))
+    r = SceneRunner(sc, device, frames_in_flight=images)
+    try:
+        owner = {}
+        for i in range(n_frames):
+            r.set_ubo(0, ubos[i])
+            owner[r.submit()] = i
+        device.wait_idle()
+        got = {img: r.targets[img].read() for img in owner}
+    finally:
+        r.destroy()
+    for img, frame in owner.items():
+        sc.ubos[0] = ubos[frame]
+        oc, od, _ = oracle.render_scene(sc, threads=4)
+        assert np.array_equal(got[img][1], od), "image %d (frame %d): depth differs" % (img, frame)
+        assert np.array_equal(got[img][0], oc), "image %d (frame %d): colour differs" % (img, frame)
+
+
+def test_two_command_buffers_share_a_target(device, oracle):
+    """Frames of different command buffers that render into one target run one after the other."""
+    a = helpers.soup_scene(160, 96, 900, 5, n_draws=3)
+    b = helpers.soup_scene(160, 96, 900, 6, n_draws=3)
+    ra, rb = SceneRunner(a, device), SceneRunner(b, device)
+    try:
+        rb.record(rb.cmd, ra.target)  # both draw into ra's target; b is submitted last
+        for _ in range(4):
+            ra.submit()
+            device.submit(rb.cmd)
+        device.wait_idle()
+        color, depth = ra.target.read()
+    finally:
+        rb.destroy()
+        ra.destroy()
+    oc, od, _ = oracle.render_scene(b, threads=4)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
 @pytest.mark.parametrize("shards", [2, 3, 8])
 def test_tile_shards_compose_the_frame(device, oracle, shards):
     """Sort-first sharding: shard k draws only tiles t with t % n == k; together they are the frame."""
