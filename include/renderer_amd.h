@@ -115,13 +115,15 @@ const char* rnd_last_error(void);
 int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out);
 int rnd_device_destroy(rnd_device dev);
 int rnd_device_wait_idle(rnd_device dev);                 /* vkDeviceWaitIdle (vk_app.cpp:412-418) */
-void* rnd_device_stream(rnd_device dev);                  /* the hipStream_t work is launched on */
+void* rnd_device_stream(rnd_device dev);                  /* the hipStream_t uploads and copies are queued on */
 int rnd_device_set_profiling(rnd_device dev, int enable); /* bracket every stage with HIP events */
 int rnd_device_stage_times(rnd_device dev, float* ms, int count);
 
 /* vk_utils::create_buffer (tools.cpp:788-835) */
 int rnd_buffer_create(rnd_device dev, uint64_t bytes, uint32_t usage, const void* init, rnd_buffer* out);
-/* vmaMapMemory / memcpy / vmaFlushAllocation / vmaUnmapMemory (base_obj_viewer_app.cpp:134-138) */
+/* vmaMapMemory / memcpy / vmaFlushAllocation / vmaUnmapMemory (base_obj_viewer_app.cpp:134-138).
+ * Frames submitted before the call keep the old bytes, frames submitted after it see the new
+ * ones.  Up to 512 bytes into a uniform buffer cost no copy at all. */
 int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t bytes);
 /* same, source already in device memory (device-to-device on the device's stream) */
 int rnd_buffer_write_device(rnd_buffer buf, uint64_t offset, const void* device_src, uint64_t bytes);
@@ -189,7 +191,10 @@ int rnd_cmd_set_tile_shard(rnd_cmd cmd, uint32_t shard_index, uint32_t shard_cou
 /* vkQueueSubmit (vk_app.cpp:463-467).  The command buffer can be resubmitted; uniform
  * buffers are read when the work executes, so a buffer_write between two submits of the
  * same command buffer changes the second frame (base_obj_viewer_app.cpp:134-138).
- * fence may be NULL. */
+ * Frames of one command buffer, and frames into one target, execute in submission order;
+ * frames of different command buffers into different targets may overlap on the GPU (the
+ * reference's frames in flight, vk_app.cpp:109-130) unless the device was created on a
+ * caller-supplied stream, which then carries everything.  fence may be NULL. */
 int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence);
 
 int rnd_fence_create(rnd_device dev, rnd_fence* out);  /* vk_app.cpp:109-130 */
