@@ -68,6 +68,7 @@ struct rnd_device_t {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     ShadeTables* tables = nullptr; /* sRGB decode/encode tables in device memory */
+    ShadeTables host_tables;       /* the same tables on the host */
     /* pinned ring for small host->device writes (the per-frame uniform block): the copy is
      * queued on the stream and the call returns without waiting for the device */
     static constexpr int STAGE_SLOTS = 64;
@@ -278,6 +279,25 @@ int report_overflow(rnd_device dev)
                 "; pass-wide list=1, clipped triangles=4): the frame is incomplete");
 }
 
+/* a colour as the shading kernel stores it: linear -> sRGB code = number of thresholds not above
+ * the value; plain UNORM = trunc(fma(c, 255, 0.5)) of the clamped value */
+uint32_t host_pack_color(const ShadeTables& tb, const float* rgba, bool srgb, bool bgra)
+{
+    auto unorm = [](float c) -> uint32_t {
+        if (!(c > 0.0f)) return 0u;
+        c = fminf(c, 1.0f);
+        return (uint32_t)fmaf(c, 255.0f, 0.5f);
+    };
+    auto encode = [&](float c) -> uint32_t {
+        uint32_t k = 0;
+        while (k < 255 && c >= tb.thr[k + 1]) ++k;
+        return k;
+    };
+    const uint32_t r = srgb ? encode(rgba[0]) : unorm(rgba[0]), g = srgb ? encode(rgba[1]) : unorm(rgba[1]),
+                   b = srgb ? encode(rgba[2]) : unorm(rgba[2]), a = unorm(rgba[3]);
+    return bgra ? (b | (g << 8) | (r << 16) | (a << 24)) : (r | (g << 8) | (b << 16) | (a << 24));
+}
+
 bool format_is_srgb(int32_t f)
 {
     return f == RND_FORMAT_R8_SRGB || f == RND_FORMAT_R8G8_SRGB || f == RND_FORMAT_R8G8B8_SRGB || f == RND_FORMAT_R8G8B8A8_SRGB ||
@@ -374,7 +394,7 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
     }
     /* sRGB tables: decode[k] = linear value of code k; thr[k] = linear value of code k-0.5;
      * lut[bucket] = number of thresholds <= the bucket's lower edge */
-    ShadeTables host_tables;
+    ShadeTables& host_tables = dev->host_tables;
     memset(&host_tables, 0, sizeof(host_tables));
     for (int k = 0; k < 256; ++k) host_tables.decode[k] = (float)srgb_to_linear(k / 255.0);
     host_tables.thr[0] = -INFINITY;
@@ -1081,6 +1101,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     }
     if (fp.pass_texture >= 0) fp.pass_tex = td[(size_t)fp.pass_texture];
     memcpy(fp.clear_color, cmd->clear_color, 16);
+    fp.clear_packed = host_pack_color(dev->host_tables, cmd->clear_color, fp.color_srgb != 0, fp.color_bgra != 0);
     fp.clear_d24 = host_depth24(cmd->clear_depth);
     fp.depth_test = (uint32_t)depth_test;
     fp.depth_write = (uint32_t)depth_test;

@@ -187,6 +187,7 @@ struct FrameParams {
     int32_t area_x0, area_y0, area_x1, area_y1;     /* inclusive render area (cleared and stored) */
     float half_w, half_h, ox, oy, pz, zmin;
     float clear_color[4];
+    uint32_t clear_packed;   /* clear_color as the target stores it (encoded, channel order applied) */
     uint32_t clear_d24;
     uint32_t depth_less;     /* 1: LESS, 0: LESS_OR_EQUAL */
     uint32_t depth_test, depth_write;

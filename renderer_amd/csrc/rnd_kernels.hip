@@ -30,18 +30,25 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-/* Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  This bijection
- * gives every XCD runs of `run` consecutive work ids (run 0 to XCD 0, run 1 to XCD 1, ...), so
- * horizontal neighbours -- which gather the same vertices and texels -- meet in one L2 while the
- * screen's rows stay spread over all XCDs for balance.  Ids past the last full group of 8 runs
- * keep their own number.  Placement only: results do not depend on it. */
-__device__ __forceinline__ uint32_t xcd_runs(uint32_t id, uint32_t n, uint32_t run)
+/* Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  A grid that
+ * covers `cols` x rows cells is walked in groups of 8 rows: inside a group, id r goes to row r % 8
+ * (= its XCD) and column r / 8.  Every XCD thus gets whole rows -- horizontal neighbours, which
+ * gather the same vertices and texels, meet in one L2 -- while the rows stay spread over all XCDs
+ * for balance.  The grid is padded to a multiple of 8 rows; cells past the last row do nothing.
+ * The one division, id / (8 * cols), is a multiply-high by magic = ceil(2^32 / (8 * cols)), exact
+ * while id * 8 * cols < 2^32 (ids stay below 2^18, 8 * cols below 2^12).  Placement only: results
+ * do not depend on it. */
+__device__ __forceinline__ void rows_of_eight(uint32_t id, uint32_t cols, uint32_t magic, uint32_t& col, uint32_t& row)
 {
-    const uint32_t group = 8u * run;
-    if (run == 0u || id >= (n / group) * group) return id;
-    const uint32_t g = id / group, r = id % group;
-    return g * group + (r & 7u) * run + (r >> 3);
+    const uint32_t group = 8u * cols;
+    const uint32_t g = __umulhi(id, magic);
+    const uint32_t r = id - g * group;
+    col = r >> 3;
+    row = g * 8u + (r & 7u);
 }
+
+static uint32_t rows_of_eight_magic(uint32_t cols) { return (uint32_t)((0x100000000ull + 8ull * cols - 1ull) / (8ull * cols)); }
+static uint32_t rows_of_eight_grid(uint32_t cols, uint32_t rows) { return ((rows + 7u) / 8u) * 8u * cols; }
 
 __device__ __forceinline__ uint32_t pack_bbox(int tx0, int ty0, int tx1, int ty1)
 {
@@ -680,14 +687,14 @@ __device__ __forceinline__ int wrap_coord(int i, int n, uint32_t tiled)
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-__device__ __forceinline__ void fetch_texel(const ShadeTables& tb, const TexDesc& t, const uint8_t* lv, int w, int x, int y, float* rgb)
+/* texel (x, y) of a level whose row `y` starts `row` texels into it */
+__device__ __forceinline__ void fetch_texel(const ShadeTables& tb, const TexDesc& t, const uint8_t* lv, uint32_t row, int x, float* rgb)
 {
-    /* a level holds at most 16384 x 16384 texels: coordinates fit 24 bits, the byte offset 32 */
-    const uint32_t off = (__umul24((uint32_t)y, (uint32_t)w) + (uint32_t)x) << 2;
-    /* texels live in device memory: say so, or a pointer read from a descriptor costs a flat load */
+    /* a level holds at most 16384 x 16384 texels: the byte offset fits 32 bits.  Texels live in
+     * device memory: say so, or a pointer read from a descriptor costs a flat load */
     typedef const __attribute__((address_space(1))) uint32_t* GlobalTexel;
-    uint32_t p = *(GlobalTexel)(lv + off);
-    uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u;
+    const uint32_t p = *(GlobalTexel)(lv + ((row + (uint32_t)x) << 2));
+    const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u;
     if (t.srgb) { rgb[0] = tb.decode[r]; rgb[1] = tb.decode[g]; rgb[2] = tb.decode[b]; }
     else { rgb[0] = (float)r / 255.0f; rgb[1] = (float)g / 255.0f; rgb[2] = (float)b / 255.0f; }
 }
@@ -695,6 +702,7 @@ __device__ __forceinline__ void fetch_texel(const ShadeTables& tb, const TexDesc
 /* pointer into LDS, typed as such so a per-lane index compiles to a ds_read and not a flat load */
 typedef const __attribute__((address_space(3))) unsigned long long* LdsLevels;
 
+/* one level at (u, v), both finite */
 template <bool PASS_TEX>
 __device__ void sample_level(const ShadeTables& tb, const TexDesc& t, LdsLevels lds_levels, uint32_t level, float u, float v, float* rgb)
 {
@@ -704,8 +712,6 @@ __device__ void sample_level(const ShadeTables& tb, const TexDesc& t, LdsLevels 
     const uint8_t* lv;
     if constexpr (PASS_TEX) lv = reinterpret_cast<const uint8_t*>(lds_levels[level]);
     else lv = t.level[level];
-    if (!finite32(u)) u = 0.0f;
-    if (!finite32(v)) v = 0.0f;
     if (t.filter_linear) {
         float fu = fma32(u, (float)w, -0.5f), fv = fma32(v, (float)h, -0.5f);
         fu = fminf(fmaxf(fu, -1.0e9f), 1.0e9f);
@@ -714,11 +720,12 @@ __device__ void sample_level(const ShadeTables& tb, const TexDesc& t, LdsLevels 
         float ax = fu - iu, ay = fv - iv;
         int x0 = wrap_coord((int)iu, w, t.tiled), x1 = wrap_coord((int)iu + 1, w, t.tiled);
         int y0 = wrap_coord((int)iv, h, t.tiled), y1 = wrap_coord((int)iv + 1, h, t.tiled);
+        const uint32_t row0 = __umul24((uint32_t)y0, (uint32_t)w), row1 = __umul24((uint32_t)y1, (uint32_t)w);
         float c00[3], c10[3], c01[3], c11[3];
-        fetch_texel(tb, t, lv, w, x0, y0, c00);
-        fetch_texel(tb, t, lv, w, x1, y0, c10);
-        fetch_texel(tb, t, lv, w, x0, y1, c01);
-        fetch_texel(tb, t, lv, w, x1, y1, c11);
+        fetch_texel(tb, t, lv, row0, x0, c00);
+        fetch_texel(tb, t, lv, row0, x1, c10);
+        fetch_texel(tb, t, lv, row1, x0, c01);
+        fetch_texel(tb, t, lv, row1, x1, c11);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float top = fma32(ax, c10[k] - c00[k], c00[k]);
@@ -729,7 +736,7 @@ __device__ void sample_level(const ShadeTables& tb, const TexDesc& t, LdsLevels 
         float fu = fminf(fmaxf(u * (float)w, -1.0e9f), 1.0e9f);
         float fv = fminf(fmaxf(v * (float)h, -1.0e9f), 1.0e9f);
         int x = wrap_coord((int)floorf(fu), w, t.tiled), y = wrap_coord((int)floorf(fv), h, t.tiled);
-        fetch_texel(tb, t, lv, w, x, y, rgb);
+        fetch_texel(tb, t, lv, __umul24((uint32_t)y, (uint32_t)w), x, rgb);
     }
 }
 
@@ -745,17 +752,25 @@ __device__ void sample_texture(const ShadeTables& tb, const TexDesc& t, LdsLevel
     float lambda = 0.5f * lod_log2(fmaxf(rx, ry));
     float max_lod = (float)(t.levels - 1);
     lambda = fminf(fmaxf(lambda, 0.0f), max_lod);
-    if (!(lambda > 0.0f) || t.levels == 1) { sample_level<PASS_TEX>(tb, t, lds_levels, 0, u, v, rgb); return; }
+    if (!finite32(u)) u = 0.0f;
+    if (!finite32(v)) v = 0.0f;
+    const bool base_only = !(lambda > 0.0f) || t.levels == 1; /* magnified: level 0 alone */
+    if (!__ballot(!base_only)) { sample_level<PASS_TEX>(tb, t, lds_levels, 0, u, v, rgb); return; }
     if (t.filter_linear) {
-        float fl = floorf(lambda);
-        uint32_t lo = (uint32_t)fl;
-        uint32_t hi = lo + 1 < t.levels ? lo + 1 : t.levels - 1;
-        float frac = lambda - fl;
+        /* Lanes of one wave usually disagree about base_only.  Rather than run the one-level and
+         * the two-level code one after the other, every lane blends two levels; a base-only lane
+         * blends level 0 with itself at fraction 0, which returns the level-0 sample unchanged. */
+        const float fl = base_only ? 0.0f : floorf(lambda);
+        const uint32_t lo = (uint32_t)fl;
+        const uint32_t hi = base_only ? 0u : (lo + 1 < t.levels ? lo + 1 : t.levels - 1);
+        const float frac = base_only ? 0.0f : lambda - fl;
         float a[3], b[3];
         sample_level<PASS_TEX>(tb, t, lds_levels, lo, u, v, a);
         sample_level<PASS_TEX>(tb, t, lds_levels, hi, u, v, b);
 #pragma unroll
         for (int k = 0; k < 3; ++k) rgb[k] = fma32(frac, b[k] - a[k], a[k]);
+    } else if (base_only) {
+        sample_level<PASS_TEX>(tb, t, lds_levels, 0, u, v, rgb);
     } else {
         float lv = ceilf(lambda + 0.5f) - 1.0f;
         lv = fminf(fmaxf(lv, 0.0f), max_lod);
@@ -979,12 +994,20 @@ constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* sample not covered by any fragment
  * held in LDS (depth, submission order, fan index; the minimum wins), then store the depth
  * words and the winning primitive of every sample with full-row coalesced stores. */
 template <int S>
-__global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
+__global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp, uint32_t magic)
 {
     __shared__ unsigned long long keys[TILE_PIXELS * S];
 
-    const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, fp.tiles_x / fp.shard_count) * fp.shard_count + fp.shard_index;
-    const int tx = (int)(tile % fp.tiles_x), ty = (int)(tile / fp.tiles_x);
+    uint32_t tile, utx, uty;
+    if (fp.shard_count == 1) {
+        rows_of_eight(blockIdx.x, fp.tiles_x, magic, utx, uty);
+        if (uty >= fp.tiles_y) return; /* padding of the grid */
+        tile = uty * fp.tiles_x + utx;
+    } else {
+        tile = blockIdx.x * fp.shard_count + fp.shard_index; /* this shard's tiles, in order */
+        utx = tile % fp.tiles_x; uty = tile / fp.tiles_x;
+    }
+    const int tx = (int)utx, ty = (int)uty;
     TileCtx tc;
     tc.px0 = tx * TILE_W; tc.py0 = ty * TILE_H;
     tc.rx0 = max(tc.px0, fp.clamp_x0); tc.ry0 = max(tc.py0, fp.clamp_y0);
@@ -1040,10 +1063,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp)
 /* One thread per pixel: shade the primitive that owns each sample (once per distinct fan
  * triangle), resolve, encode, store.  Workgroup = 32x8 pixels, lanes along x. */
 #ifndef SHADE_WAVES
-#define SHADE_WAVES 6 /* waves per SIMD the single-sample shading kernel is compiled for */
+#define SHADE_WAVES 8 /* waves per SIMD the single-sample shading kernel is compiled for: 64 VGPRs; the few spilled dwords cost less than the lost occupancy */
 #endif
 template <int S>
-__global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(FrameParams fp)
+__global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(FrameParams fp, uint32_t blocks_x, uint32_t magic)
 {
     __shared__ ShadeTables tb;
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
@@ -1052,9 +1075,9 @@ __global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(Frame
     stage_tables(tb, fp.tables);
     if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
     __syncthreads();
-    const uint32_t blocks_x = (fp.width + 31u) / 32u;
-    const uint32_t blk = xcd_runs(blockIdx.x, gridDim.x, blocks_x);
-    const int x = (int)((blk % blocks_x) * 32u + (threadIdx.x & 31u)), y = (int)((blk / blocks_x) * 8u + (threadIdx.x >> 5));
+    uint32_t bx, by;
+    rows_of_eight(blockIdx.x, blocks_x, magic, bx, by);
+    const int x = (int)(bx * 32u + (threadIdx.x & 31u)), y = (int)(by * 8u + (threadIdx.x >> 5));
     if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) return;
     if (fp.shard_count > 1) {
         const uint32_t tile = (uint32_t)(y >> TILE_SHIFT) * fp.tiles_x + (uint32_t)(x >> TILE_SHIFT);
@@ -1068,6 +1091,11 @@ __global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(Frame
     } else {
         vis[0] = fp.vis[pi];
     }
+    /* no fragment landed on the pixel: the clear colour, encoded once on the host */
+    bool untouched = true;
+#pragma unroll
+    for (int s = 0; s < S; ++s) untouched = untouched && vis[s] == VIS_NONE;
+    if (untouched) { reinterpret_cast<uint32_t*>(fp.color)[pi] = fp.clear_packed; return; }
     float smp[S][4];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -1161,15 +1189,19 @@ void launch_tile(const FrameParams& fp, hipStream_t s)
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     const uint32_t mine = n_tiles > fp.shard_index ? (n_tiles - fp.shard_index + fp.shard_count - 1) / fp.shard_count : 0;
     if (!mine) return;
-    if (fp.samples == 4) hipLaunchKernelGGL(k_tile<4>, dim3(mine), dim3(TILE_THREADS), 0, s, fp);
-    else hipLaunchKernelGGL(k_tile<1>, dim3(mine), dim3(TILE_THREADS), 0, s, fp);
+    const uint32_t grid = fp.shard_count == 1 ? rows_of_eight_grid(fp.tiles_x, fp.tiles_y) : mine;
+    const uint32_t magic = rows_of_eight_magic(fp.tiles_x);
+    if (fp.samples == 4) hipLaunchKernelGGL(k_tile<4>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
+    else hipLaunchKernelGGL(k_tile<1>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
 }
 
 void launch_shade(const FrameParams& fp, hipStream_t s)
 {
-    const dim3 grid(((fp.width + 31) / 32) * ((fp.height + 7) / 8));
-    if (fp.samples == 4) hipLaunchKernelGGL(k_shade<4>, grid, dim3(256), 0, s, fp);
-    else hipLaunchKernelGGL(k_shade<1>, grid, dim3(256), 0, s, fp);
+    const uint32_t blocks_x = (fp.width + 31) / 32, blocks_y = (fp.height + 7) / 8;
+    const dim3 grid(rows_of_eight_grid(blocks_x, blocks_y));
+    const uint32_t magic = rows_of_eight_magic(blocks_x);
+    if (fp.samples == 4) hipLaunchKernelGGL(k_shade<4>, grid, dim3(256), 0, s, fp, blocks_x, magic);
+    else hipLaunchKernelGGL(k_shade<1>, grid, dim3(256), 0, s, fp, blocks_x, magic);
 }
 
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
