@@ -2,8 +2,8 @@
 // obj_sub_geometry, src/libs/vk_utils/vk_utils/obj_loader.hpp:61-89) over the HIP library's
 // buffers, and the upload step of init_obj_geometry (obj_loader.cpp:93-310): one interleaved
 // vertex buffer for all shapes (pos3 [normal3] [uv2]), one uint32 index buffer with indices
-// local to each sub-geometry, and the normalising model transform.  Parsing OBJ files is not
-// part of the draw path; shapes arrive as arrays (the reference's assets are Git-LFS stubs).
+// local to each sub-geometry, and the normalising model transform.  Shapes arrive as arrays, from
+// obj_loader.hpp or from a procedural mesh (the reference's own assets are Git-LFS stubs).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -42,15 +42,24 @@ struct shape_data {
     std::vector<uint32_t> indices;
 };
 
-// Builds the interleaved buffers and the sub-geometry table, uploads them, and derives
-// model_transform = translate(offset) * scale(1/largest half extent) like the reference
-// (obj_loader.cpp:294-307), with fabsf where the reference's unqualified abs() may truncate.
-inline ERROR_TYPE upload_model(rnd_device dev, const std::vector<shape_data>& shapes, obj_model& model)
+// The host half of init_obj_geometry's tail (obj_loader.cpp:144-205, 294-307): the interleaved
+// vertex data, the index data, the sub-geometry table, and model_transform = translate(offset) *
+// scale(1 / largest half extent), with fabs where the reference's unqualified abs() may truncate
+// and a bounding box that starts empty (the reference's starts at numeric_limits<float>::min()).
+struct model_buffers {
+    std::vector<float> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<obj_sub_geometry> sub_geometries;
+    glm_lite::mat4 model_transform{1.0f};
+};
+
+inline ERROR_TYPE build_model_buffers(const std::vector<shape_data>& shapes, model_buffers& out)
 {
-    std::vector<float> vb;
-    std::vector<uint32_t> ib;
+    std::vector<float>& vb = out.vertices;
+    std::vector<uint32_t>& ib = out.indices;
+    vb.clear(); ib.clear(); out.sub_geometries.clear();
     glm_lite::vec3 min_pos{1e30f, 1e30f, 1e30f}, max_pos{-1e30f, -1e30f, -1e30f};
-    model.sub_geometries.clear();
+    uint32_t start_vertex = 0;
     for (const shape_data& s : shapes) {
         obj_sub_geometry g;
         g.format.push_back(RND_FORMAT_R32G32B32_SFLOAT);
@@ -59,6 +68,7 @@ inline ERROR_TYPE upload_model(rnd_device dev, const std::vector<shape_data>& sh
         g.vertices_offset = (uint32_t)(vb.size() * sizeof(float));
         g.indices_offset = (uint32_t)ib.size();
         g.indices_size = (uint32_t)s.indices.size();
+        g.indices_bias = start_vertex;
         const size_t n = s.positions.size() / 3;
         for (size_t v = 0; v < n; ++v) {
             const float* p = &s.positions[v * 3];
@@ -69,12 +79,10 @@ inline ERROR_TYPE upload_model(rnd_device dev, const std::vector<shape_data>& sh
             if (!s.uvs.empty()) vb.insert(vb.end(), &s.uvs[v * 2], &s.uvs[v * 2] + 2);
         }
         ib.insert(ib.end(), s.indices.begin(), s.indices.end());
-        model.sub_geometries.push_back(g);
+        start_vertex += (uint32_t)n;
+        out.sub_geometries.push_back(g);
     }
     if (vb.empty() || ib.empty()) RAISE_ERROR_FATAL(-1, "model holds no geometry");
-    RND_CHECK(rnd_buffer_create(dev, vb.size() * sizeof(float), RND_BUFFER_USAGE_VERTEX, vb.data(), model.vertex_buffer.put()));
-    RND_CHECK(rnd_buffer_create(dev, ib.size() * sizeof(uint32_t), RND_BUFFER_USAGE_INDEX, ib.data(), model.index_buffer.put()));
-
     glm_lite::vec3 offset = (max_pos - min_pos) * 0.5f;
     const float sx = std::max(std::fabs(min_pos.x - offset.x), std::fabs(max_pos.x - offset.x));
     const float sy = std::max(std::fabs(min_pos.y - offset.y), std::fabs(max_pos.y - offset.y));
@@ -83,8 +91,20 @@ inline ERROR_TYPE upload_model(rnd_device dev, const std::vector<shape_data>& sh
     final_scale = sz > final_scale ? 1.0f / sz : 1.0f / final_scale;
     const glm_lite::vec3 scale{final_scale, final_scale, final_scale};
     offset = (min_pos + (max_pos - min_pos) * 0.5f) * final_scale;
-    model.model_transform = glm_lite::translate(glm_lite::mat4(1.0f), offset);
-    model.model_transform = glm_lite::scale(model.model_transform, scale);
+    out.model_transform = glm_lite::translate(glm_lite::mat4(1.0f), offset);
+    out.model_transform = glm_lite::scale(out.model_transform, scale);
+    RAISE_ERROR_OK();
+}
+
+// ... and the device half: create_buffer for both (obj_loader.cpp:207-292)
+inline ERROR_TYPE upload_model(rnd_device dev, const std::vector<shape_data>& shapes, obj_model& model)
+{
+    model_buffers b;
+    PASS_ERROR(build_model_buffers(shapes, b));
+    RND_CHECK(rnd_buffer_create(dev, b.vertices.size() * sizeof(float), RND_BUFFER_USAGE_VERTEX, b.vertices.data(), model.vertex_buffer.put()));
+    RND_CHECK(rnd_buffer_create(dev, b.indices.size() * sizeof(uint32_t), RND_BUFFER_USAGE_INDEX, b.indices.data(), model.index_buffer.put()));
+    model.sub_geometries = b.sub_geometries;
+    model.model_transform = b.model_transform;
     RAISE_ERROR_OK();
 }
 
