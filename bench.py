@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the draw path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|0] [--mode views|tiles]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4] [--mode views|tiles]
 
 One step = one frame: write the 320-byte uniform block (a new camera, as the reference's
 draw_frame does every frame, base_obj_viewer_app.cpp:90-141) and submit the pre-recorded
@@ -42,6 +42,8 @@ def build_scene(cfg):
         return scenes.config2()
     if cfg == 3:
         return scenes.config3()
+    if cfg == 4:
+        return scenes.config4_view(0)  # one of the 64 views; each rank renders its own (orbit_ubo)
     raise SystemExit("unknown --config %r" % cfg)
 
 

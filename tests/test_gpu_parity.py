@@ -59,3 +59,35 @@ def test_config2_full(device, oracle):
     submitted back to front (the worst case for early depth rejection)."""
     mism = compare(scenes.config2(), device, oracle, threads=16)
     assert mism == 0
+
+
+def test_config3_full_and_tile_shards(device, oracle):
+    """BASELINE configs[3] at full size: 7680x4320, 40 000 instances (12.8 M triangles).  The whole
+    frame against the oracle, and the property the multi-GPU mode rests on: the frames of two tile
+    shards, composed by tile owner, are the unsharded frame."""
+    sc = scenes.config3()
+    r = SceneRunner(sc, device)
+    try:
+        color, depth = r.render()
+        shards = []
+        for k in range(2):
+            r.cmd.set_tile_shard(k, 2)
+            shards.append(r.render())
+    finally:
+        r.destroy()
+    ocolor, odepth, _ = oracle.render_scene(sc, threads=16)
+    assert np.array_equal(depth, odepth)
+    assert np.abs(color.astype(np.int32) - ocolor.astype(np.int32)).max() <= 1
+    tiles_x = (sc.width + 31) // 32
+    ty, tx = np.mgrid[0:sc.height, 0:sc.width] // 32
+    owner = (ty * tiles_x + tx) % 2
+    for k, (c, d) in enumerate(shards):
+        mine = owner == k
+        assert np.array_equal(c[mine], color[mine]) and np.array_equal(d[mine], depth[mine])
+
+
+def test_config4_view_full(device, oracle):
+    """One view of BASELINE configs[4] at full size: 1920x1080 over a 2237x2237-quad grid
+    (10 008 338 triangles, most of them smaller than a pixel)."""
+    mism = compare(scenes.config4_view(5), device, oracle, threads=16)
+    assert mism == 0
