@@ -551,35 +551,42 @@ __device__ __forceinline__ bool tri_is_small(const RasterTri& t)
     return ext < (1 << 14);
 }
 
-/* one lane walks its own (small) triangle's box.  With one sample per pixel the three edge
- * values are stepped incrementally: one add per edge per pixel, multiplies only at the start. */
+/* one lane walks its own (small) triangle's box, as ONE loop over the box's pixels in row order:
+ * the wave then runs for as many steps as its largest box has pixels.  (As a loop over rows around
+ * a loop over columns it would run for the tallest box's height times the widest box's width, which
+ * for triangles of mixed orientation is several times more.)  With one sample per pixel the three
+ * edge values are stepped incrementally: one add per edge per pixel, multiplies only at the start. */
 template <int S>
 __device__ __forceinline__ void raster_lane(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int x1, int y1)
 {
     EdgeSetup<int32_t, S> es;
     es.init(fp, t);
+    const int w = x1 - x0 + 1;
+    const int count = w * (y1 - y0 + 1);
     if constexpr (S == 1) {
         const int32_t px = x0 * 256 + 128, py = y0 * 256 + 128;
         /* the ownership bias is folded into the start values and taken out again for the depth */
-        int32_t r0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0) - es.bias0;
-        int32_t r1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1) - es.bias1;
-        int32_t r2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2) - es.bias2;
+        int32_t e0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0) - es.bias0;
+        int32_t e1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1) - es.bias1;
+        int32_t e2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2) - es.bias2;
         const int32_t sx0 = -(es.dy0 << 8), sx1 = -(es.dy1 << 8), sx2 = -(es.dy2 << 8); /* one pixel right */
-        const int32_t sy0 = es.dx0 << 8, sy1 = es.dx1 << 8, sy2 = es.dx2 << 8;          /* one pixel down */
-        uint32_t row = (uint32_t)((y0 - tc.py0) * TILE_W + (x0 - tc.px0));
-        for (int y = y0; y <= y1; ++y) {
-            int32_t e0 = r0, e1 = r1, e2 = r2;
-            uint32_t pix = row;
-            for (int x = x0; x <= x1; ++x) {
-                if ((e0 | e1 | e2) >= 0) es.emit(tc, pix, e1 + es.bias1, e2 + es.bias2);
-                e0 += sx0; e1 += sx1; e2 += sx2;
-                ++pix;
-            }
-            r0 += sy0; r1 += sy1; r2 += sy2;
-            row += TILE_W;
+        /* from the last pixel of a row to the first of the next: one down, w - 1 back */
+        const int32_t nl0 = (es.dx0 << 8) - (w - 1) * sx0, nl1 = (es.dx1 << 8) - (w - 1) * sx1, nl2 = (es.dx2 << 8) - (w - 1) * sx2;
+        uint32_t pix = (uint32_t)((y0 - tc.py0) * TILE_W + (x0 - tc.px0));
+        int col = 0;
+        for (int i = 0; i < count; ++i) {
+            if ((e0 | e1 | e2) >= 0) es.emit(tc, pix, e1 + es.bias1, e2 + es.bias2);
+            const bool last = ++col == w;
+            e0 += last ? nl0 : sx0; e1 += last ? nl1 : sx1; e2 += last ? nl2 : sx2;
+            pix += last ? (uint32_t)(TILE_W - w + 1) : 1u;
+            if (last) col = 0;
         }
     } else {
-        for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) es.pixel(tc, x, y);
+        int x = x0, y = y0;
+        for (int i = 0; i < count; ++i) {
+            es.pixel(tc, x, y);
+            if (++x > x1) { x = x0; ++y; }
+        }
     }
 }
 
