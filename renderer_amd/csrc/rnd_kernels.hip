@@ -631,15 +631,87 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
     return true;
 }
 
-/* Who walks a triangle's box.  A lane walking its own box costs the wave as many steps as the
- * largest box among its lanes; the whole wave walking one box costs a fixed set-up per triangle.
- * So: boxes up to LANE_PIXELS always go by lane; when at least a quarter of the wave holds larger
- * boxes (a scene of mid-size triangles: the lanes are balanced anyway) every box goes by lane;
- * otherwise the few large ones are taken by the whole wave. */
-constexpr int LANE_PIXELS = 64;
+/* Who walks a triangle's box.
+ *
+ * A lane walking its own box costs the wave as many steps as the largest box among its lanes, so it
+ * is used as it stands only while every box of the wave has at most CHUNK_PIXELS pixels (a mesh of
+ * pixel-sized triangles).  Otherwise the boxes are cut into chunks of CHUNK_PIXELS consecutive
+ * pixels (in the row order of the one-loop walk) and the chunks, not the triangles, are dealt to the
+ * lanes: an exclusive scan of the chunk counts numbers them, lane l of round r takes chunk 64 r + l,
+ * finds the triangle that owns it by a binary search over the scan (ds_bpermute), fetches that
+ * triangle from its lane and walks the chunk.  Every lane then has at most CHUNK_PIXELS steps per
+ * round whatever the mix of box sizes, and nothing is left to the whole-wave path except triangles
+ * too large for 32-bit edge products. */
+constexpr int CHUNK_PIXELS = 32;
 
-/* One batch: every lane holds (at most) one triangle.  Small boxes are walked by their own lane;
- * the others are taken one at a time by the whole wave (ballot, broadcast, 8x8 blocks). */
+template <int S>
+__device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileCtx& tc, bool active, const RasterTri& t,
+                                              int x0, int y0, int x1, int y1)
+{
+    const int lane = (int)lane_id();
+    const int w = x1 - x0 + 1;
+    const int area = active ? w * (y1 - y0 + 1) : 0;
+    const int n = (area + CHUNK_PIXELS - 1) / CHUNK_PIXELS;
+    int incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    const int excl = incl - n;
+    const int total = __shfl(incl, 63);
+    for (int base = 0; base < total; base += 64) {
+        const int c = base + lane;
+        /* owner: the last lane whose first chunk number is not above c (lanes without chunks share
+         * their successor's number and lose to it) */
+        int o = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int cand = o + step;
+            const int first = __shfl(excl, cand & 63);
+            if (cand < 64 && first <= c) o = cand;
+        }
+        RasterTri u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { u.x[k] = __shfl(t.x[k], o); u.y[k] = __shfl(t.y[k], o); u.z[k] = __shfl(t.z[k], o); }
+        u.payload_lo = (uint32_t)__shfl((int)t.payload_lo, o);
+        u.slot = (uint32_t)__shfl((int)t.slot, o);
+        const int ox0 = __shfl(x0, o), oy0 = __shfl(y0, o), ow = __shfl(w, o), oarea = __shfl(area, o), ofirst = __shfl(excl, o);
+        if (c >= total) continue;
+        const int k0 = (c - ofirst) * CHUNK_PIXELS, k1 = min(k0 + CHUNK_PIXELS, oarea);
+        /* row and column of pixel k0: k0 / ow by a 16-bit reciprocal, exact for k0 < 1024 and ow <= 32
+         * (65536 / ow is an integer only for powers of two, where the float quotient is exact) */
+        const uint32_t recip = (uint32_t)ceilf(65536.0f / (float)ow);
+        const int row = (int)(((uint32_t)k0 * recip) >> 16);
+        int col = k0 - row * ow;
+        EdgeSetup<int32_t, S> es;
+        es.init(fp, u);
+        if constexpr (S == 1) {
+            const int32_t px = (ox0 + col) * 256 + 128, py = (oy0 + row) * 256 + 128;
+            int32_t e0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0) - es.bias0;
+            int32_t e1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1) - es.bias1;
+            int32_t e2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2) - es.bias2;
+            const int32_t sx0 = -(es.dy0 << 8), sx1 = -(es.dy1 << 8), sx2 = -(es.dy2 << 8);
+            const int32_t nl0 = (es.dx0 << 8) - (ow - 1) * sx0, nl1 = (es.dx1 << 8) - (ow - 1) * sx1, nl2 = (es.dx2 << 8) - (ow - 1) * sx2;
+            uint32_t pix = (uint32_t)((oy0 + row - tc.py0) * TILE_W + (ox0 + col - tc.px0));
+            for (int i = k0; i < k1; ++i) {
+                if ((e0 | e1 | e2) >= 0) es.emit(tc, pix, e1 + es.bias1, e2 + es.bias2);
+                const bool last = ++col == ow;
+                e0 += last ? nl0 : sx0; e1 += last ? nl1 : sx1; e2 += last ? nl2 : sx2;
+                pix += last ? (uint32_t)(TILE_W - ow + 1) : 1u;
+                if (last) col = 0;
+            }
+        } else {
+            int x = ox0 + col, y = oy0 + row;
+            for (int i = k0; i < k1; ++i) {
+                es.pixel(tc, x, y);
+                if (++x >= ox0 + ow) { x = ox0; ++y; }
+            }
+        }
+    }
+}
+
+/* One batch: every lane holds (at most) one triangle. */
 template <int S>
 __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCtx& tc, bool have, const RasterTri& t)
 {
@@ -647,11 +719,11 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
     const bool hit = have && tri_box_in_tile(fp, tc, t, x0, y0, x1, y1);
     const int area = hit ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
     const bool small = tri_is_small(t);
-    const int crowd = __popcll(__ballot(hit && area > LANE_PIXELS && small));
-    const bool by_lane = hit && small && (area <= LANE_PIXELS || crowd >= 16);
     if (fp.debug_flags & 128u) { if (hit && t.z[0] == 123.0f) tc.keys[0] = 0; return; }
-    if (by_lane) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
-    uint64_t big = __ballot(hit && !by_lane);
+    if (__ballot(hit && small && area > CHUNK_PIXELS)) raster_chunks<S>(fp, tc, hit && small, t, x0, y0, x1, y1);
+    else if (hit && small) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
+    /* too large for 32-bit edge products: one at a time by the whole wave (ballot, broadcast, 8x8 blocks) */
+    uint64_t big = __ballot(hit && !small);
     while (big) {
         const int src = __ffsll((unsigned long long)big) - 1;
         big &= big - 1;
