@@ -634,7 +634,7 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
 /* Who walks a triangle's box.
  *
  * A lane walking its own box costs the wave as many steps as the largest box among its lanes, so it
- * is used as it stands only while every box of the wave has at most CHUNK_PIXELS pixels (a mesh of
+ * is used as it stands only while every box of the wave has at most DIRECT_PIXELS pixels (a mesh of
  * pixel-sized triangles).  Otherwise the boxes are cut into chunks of CHUNK_PIXELS consecutive
  * pixels (in the row order of the one-loop walk) and the chunks, not the triangles, are dealt to the
  * lanes: an exclusive scan of the chunk counts numbers them, lane l of round r takes chunk 64 r + l,
@@ -642,7 +642,8 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
  * triangle from its lane and walks the chunk.  Every lane then has at most CHUNK_PIXELS steps per
  * round whatever the mix of box sizes, and nothing is left to the whole-wave path except triangles
  * too large for 32-bit edge products. */
-constexpr int CHUNK_PIXELS = 32;
+constexpr int DIRECT_PIXELS = 32; /* measured: 16-pixel chunks balance best, but a wave of boxes up to 32 pixels is quicker walked as it is */
+constexpr int CHUNK_PIXELS = 16;
 
 template <int S>
 __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileCtx& tc, bool active, const RasterTri& t,
@@ -720,7 +721,7 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
     const int area = hit ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
     const bool small = tri_is_small(t);
     if (fp.debug_flags & 128u) { if (hit && t.z[0] == 123.0f) tc.keys[0] = 0; return; }
-    if (__ballot(hit && small && area > CHUNK_PIXELS)) raster_chunks<S>(fp, tc, hit && small, t, x0, y0, x1, y1);
+    if (__ballot(hit && small && area > DIRECT_PIXELS)) raster_chunks<S>(fp, tc, hit && small, t, x0, y0, x1, y1);
     else if (hit && small) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
     /* too large for 32-bit edge products: one at a time by the whole wave (ballot, broadcast, 8x8 blocks) */
     uint64_t big = __ballot(hit && !small);
