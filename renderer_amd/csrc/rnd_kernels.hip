@@ -590,25 +590,17 @@ __device__ __forceinline__ void raster_lane(const FrameParams& fp, const TileCtx
     }
 }
 
-/* the whole wave walks one triangle's box in 8x8 pixel blocks (t and the box are wave-uniform) */
+/* the whole wave walks one triangle's box in 8x8 pixel blocks (t and the box are wave-uniform):
+ * the path of triangles 64 pixels or more across, whose edge products need 64 bits */
 template <int S>
 __device__ __forceinline__ void raster_wave(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int x1, int y1)
 {
     const int lx = (int)(lane_id() & 7u), ly = (int)(lane_id() >> 3);
-    if (tri_is_small(t)) {
-        EdgeSetup<int32_t, S> es;
-        es.init(fp, t);
-        for (int by = y0; by <= y1; by += 8) for (int bx = x0; bx <= x1; bx += 8) {
-            const int x = bx + lx, y = by + ly;
-            if (x <= x1 && y <= y1) es.pixel(tc, x, y);
-        }
-    } else {
-        EdgeSetup<int64_t, S> es;
-        es.init(fp, t);
-        for (int by = y0; by <= y1; by += 8) for (int bx = x0; bx <= x1; bx += 8) {
-            const int x = bx + lx, y = by + ly;
-            if (x <= x1 && y <= y1) es.pixel(tc, x, y);
-        }
+    EdgeSetup<int64_t, S> es;
+    es.init(fp, t);
+    for (int by = y0; by <= y1; by += 8) for (int bx = x0; bx <= x1; bx += 8) {
+        const int x = bx + lx, y = by + ly;
+        if (x <= x1 && y <= y1) es.pixel(tc, x, y);
     }
 }
 
@@ -1038,18 +1030,26 @@ template <int S, typename Fetch>
 __device__ __forceinline__ void raster_stream(const FrameParams& fp, const TileCtx& tc, uint32_t n, Fetch fetch)
 {
     if (n == 0) return;
-    const uint32_t tid = threadIdx.x;
+    /* entry of a thread in the batch that starts at `base`: consecutive (coalesced loads) unless
+     * that would leave a whole wave idle; such a batch is dealt round-robin to the four waves */
+    auto entry_of = [&](uint32_t base) -> uint32_t {
+        if (base >= n) return n;
+        if (n - base > (uint32_t)(TILE_THREADS - 64)) return base + threadIdx.x < n ? base + threadIdx.x : n;
+        const uint32_t j = (threadIdx.x & 63u) * (TILE_THREADS / 64u) + (threadIdx.x >> 6);
+        return j < n - base ? base + j : n;
+    };
     TileEntry e_in = {0, 0, 0, 0}, e_mid = {0, 0, 0, 0};
     RasterTri t_cur, t_next;
     bool h_cur = false, h_next = false, h_mid = false, h_in = false;
     {
         TileEntry e0;
-        h_cur = tid < n && fetch(tid, e0);
+        const uint32_t i0 = entry_of(0), i1 = entry_of(TILE_THREADS);
+        h_cur = i0 < n && fetch(i0, e0);
         if (h_cur) h_cur = load_raster_tri(fp, e0, t_cur);
-        h_mid = tid + TILE_THREADS < n && fetch(tid + TILE_THREADS, e_mid);
+        h_mid = i1 < n && fetch(i1, e_mid);
     }
     for (uint32_t base = 0; base < n; base += TILE_THREADS) {
-        const uint32_t i2 = base + 2u * TILE_THREADS + tid;
+        const uint32_t i2 = entry_of(base + 2u * TILE_THREADS);
         h_in = i2 < n && fetch(i2, e_in);
         h_next = h_mid;
         if (h_next) h_next = load_raster_tri(fp, e_mid, t_next);
