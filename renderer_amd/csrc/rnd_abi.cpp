@@ -1093,6 +1093,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     } else {
         fp.clamp_x0 = 0; fp.clamp_y0 = 0; fp.clamp_x1 = -1; fp.clamp_y1 = -1;
     }
+    fp.direct_index = n == 1 ? 1u : 0u;
     fp.pass_shader = n ? ds[0].shader : -1;
     fp.pass_texture = n ? ds[0].texture : -1;
     for (size_t i = 1; i < n; ++i) {

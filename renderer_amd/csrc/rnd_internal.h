@@ -68,7 +68,8 @@ struct LargeEntry {
     uint32_t pad[3];
 };
 
-/* Per primitive slot, written by setup for every primitive that survives: what shading needs.
+/* Per primitive slot, written by setup for every primitive that survives (in a one-draw pass only for
+ * clipped ones: FrameParams::direct_index): what shading needs.
  * Unclipped: v0..v2 index svtx[] in the primitive's own corner order.
  * Clipped (FLAG_CLIPPED in draw_flags): v0 = index of its first ClipTri. */
 struct PrimRec {
@@ -176,7 +177,7 @@ struct FrameParams {
                                 (equal low address bits would pile every tile onto the same memory channels) */
     uint8_t* color;          /* resolved colour, width*height*4 */
     uint32_t* depth;         /* width*height*samples */
-    uint32_t* vis;           /* width*height*samples: owning primitive slot | fan index << 28, or 0xFFFFFFFF */
+    uint32_t* vis;           /* width*height*samples: owning primitive slot | fan index << 28 | clipped << 31, or 0xFFFFFFFF */
     const struct ShadeTables* tables; /* sRGB decode / encode tables */
     uint32_t n_draws, n_vchunks, n_tchunks, n_textures;
     uint32_t width, height, samples;
@@ -191,6 +192,8 @@ struct FrameParams {
     uint32_t clear_d24;
     uint32_t depth_less;     /* 1: LESS, 0: LESS_OR_EQUAL */
     uint32_t depth_test, depth_write;
+    uint32_t direct_index;   /* 1: the pass is one draw, so a primitive's slot is its triangle number and shading reads the
+                                index buffer itself; unclipped primitives then get no PrimRec */
     int32_t pass_shader;     /* shader of every draw of the pass, or -1 when they differ */
     int32_t pass_texture;    /* texture index of every draw (-1: none bound), or -2 when they differ */
     TexDesc pass_tex;        /* textures[pass_texture] by value */

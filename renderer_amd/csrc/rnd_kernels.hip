@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
                 const uint32_t v0 = d.svtx_base + pf.idx[0], v1 = d.svtx_base + pf.idx[1], v2 = d.svtx_base + pf.idx[2];
                 /* what shading needs, in the primitive's own corner order */
                 PrimRec pr = {v0, v1, v2, c.draw};
-                fp.prim_rec[slot] = pr;
+                if (!fp.direct_index) fp.prim_rec[slot] = pr;
                 /* what rasterisation needs: corners ordered for positive area */
                 e.a = d.svtx_base + pf.idx[t.corner[0]];
                 e.b = d.svtx_base + pf.idx[t.corner[1]];
@@ -470,7 +470,7 @@ struct TileCtx {
 struct RasterTri {
     int32_t x[3], y[3];
     float z[3];
-    uint32_t payload_lo; /* bits 0..7 fan index; the order word is added per depth mode */
+    uint32_t payload_lo; /* bits 0..2 fan index, bit 3 clipped; the order word is added per depth mode */
     uint32_t slot;
 };
 
@@ -612,7 +612,7 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
         const ClipTri* ct = &fp.clip_tris[e.a];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { t.x[k] = ct->x[k]; t.y[k] = ct->y[k]; t.z[k] = ct->z[k]; }
-        t.payload_lo = (e.slot_flags >> ENTRY_SUB_SHIFT) & 7u;
+        t.payload_lo = ((e.slot_flags >> ENTRY_SUB_SHIFT) & 7u) | 8u;
         return true;
     }
     const SVtx a = fp.svtx[e.a], b = fp.svtx[e.b], c = fp.svtx[e.c];
@@ -941,10 +941,18 @@ __device__ __forceinline__ void to_parent(const float* bary, float* q)
 
 /* colour of the fragment of (slot, sub) at pixel (x, y) */
 __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
-                            uint32_t slot, uint32_t sub, int x, int y, float* rgba)
+                            uint32_t slot, uint32_t sub, bool clipped, int x, int y, float* rgba)
 {
-    const PrimRec pr = fp.prim_rec[slot];
-    const bool clipped = (pr.draw_flags & FLAG_CLIPPED) != 0u;
+    PrimRec pr;
+    if (fp.direct_index && !clipped) {
+        /* a pass of one draw: the slot is the triangle's number, its corners come from the index buffer */
+        const DrawStatic& d = fp.draws[0];
+        const uint32_t* ip = d.ib + (size_t)slot * 3;
+        pr.v0 = d.svtx_base + load_u32(ip); pr.v1 = d.svtx_base + load_u32(ip + 1); pr.v2 = d.svtx_base + load_u32(ip + 2);
+        pr.draw_flags = 0;
+    } else {
+        pr = fp.prim_rec[slot];
+    }
     uint32_t vtx[3] = {pr.v0, pr.v1, pr.v2};
     uint32_t draw = pr.draw_flags & SLOT_MASK;
     if (clipped) {
@@ -1134,7 +1142,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp, uint32_t 
         uint32_t vis = VIS_NONE;
         if (k != clear_key) {
             const uint32_t low = (uint32_t)(k >> 8);
-            vis = (fp.depth_less ? low : ~low) | ((uint32_t)(k & 7ull) << ENTRY_SUB_SHIFT);
+            vis = ((fp.depth_less ? low : ~low) & SLOT_MASK) | ((uint32_t)(k & 15ull) << ENTRY_SUB_SHIFT);
         }
         fp.vis[gi] = vis;
     }
@@ -1189,7 +1197,7 @@ __global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(Frame
         } else if (fp.debug_flags & 1u) {
             smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.5f;
         } else {
-            shade_pixel(fp, tb, (LdsLevels)pass_levels, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, x, y, smp[s]);
+            shade_pixel(fp, tb, (LdsLevels)pass_levels, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, (vis[s] & FLAG_CLIPPED) != 0u, x, y, smp[s]);
         }
     }
     float acc[4];
