@@ -266,6 +266,45 @@ def test_frames_in_flight_keep_their_uniforms(device, oracle, images):
         assert np.array_equal(got[img][0], oc), "image %d (frame %d): colour differs" % (img, frame)
 
 
+def test_uniform_write_paths(device, oracle):
+    """The small uniform write is held back and travels with the submits; everything else that
+    touches the buffer must still see it: a read-back, a write to another range (which stores the
+    held-back one first), a write too large to be held back, a device-side copy -- with frames in
+    flight all the while."""
+    sc = scenes.config0(256, 144, tex_size=64, segments=24, rings=12)
+    model = np.asarray(sc.ubos[0][48:64], dtype=np.float32).reshape(4, 4)
+
+    def ubo_for(i):
+        cam = hm.Camera()
+        cam.eye_position = np.array([0.3 * np.cos(i), 0.2 * np.sin(i), -2.0 - 0.1 * i], dtype=np.float32)
+        return hm.global_ubo(cam, model, sc.width, sc.height)
+
+    r = SceneRunner(sc, device, frames_in_flight=2)
+    spare = api.Buffer(device, api.BUFFER_USAGE_UNIFORM, nbytes=2048)
+    try:
+        r.set_ubo(0, ubo_for(1))                      # held back
+        assert np.array_equal(r.ubos[0].read().view(np.float32), ubo_for(1))  # read-back sees it
+        r.submit()
+        r.set_ubo(0, ubo_for(2))                      # replaces the held-back bytes
+        spare.write(np.arange(80, dtype=np.float32))  # another range: the first is stored to memory
+        r.submit()                                    # no held-back write for the frame's buffer: reads memory
+        spare.write(np.zeros(256, dtype=np.float32))  # 1 KiB: too large to hold back
+        r.submit()
+        big = np.concatenate([ubo_for(3), np.zeros(176, np.float32)])
+        r.ubos[0].write(big[:80])                     # held back again
+        assert np.array_equal(spare.read(1024).view(np.float32), np.zeros(256, np.float32))
+        last = r.submit()
+        device.wait_idle()
+        color, depth = r.targets[last].read()
+        assert np.array_equal(r.ubos[0].read().view(np.float32), ubo_for(3))
+    finally:
+        spare.destroy()
+        r.destroy()
+    sc.ubos[0] = ubo_for(3)
+    oc, od, _ = oracle.render_scene(sc, threads=4)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
 def test_two_command_buffers_share_a_target(device, oracle):
     """Frames of different command buffers that render into one target run one after the other."""
     a = helpers.soup_scene(160, 96, 900, 5, n_draws=3)
