@@ -208,17 +208,37 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 {
     const FrameParams& fp = args.fp;
     const UniformPatch& up = args.up;
-    uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_vchunks) return;
     const Chunk c = fp.vchunks[chunk];
     const DrawStatic& d = fp.draws[c.draw];
+    /* the vertex's attributes are requested first: they do not depend on the matrices, whose
+     * construction (loads, multiply-adds, broadcasts) then runs under their latency */
+    const uint32_t v = c.first + lane_id();
+    const bool live = v < d.vert_count;
+    float pos[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f}, uv[2] = {0.0f, 0.0f};
+    if (live) {
+        const uint8_t* rec = d.vb + (size_t)v * d.stride;
+        const float* p = reinterpret_cast<const float*>(rec + d.off_pos);
+        pos[0] = load_f32(p); pos[1] = load_f32(p + 1); pos[2] = load_f32(p + 2);
+        if (d.off_uv >= 0) {
+            const float* q = reinterpret_cast<const float*>(rec + d.off_uv);
+            uv[0] = load_f32(q); uv[1] = load_f32(q + 1);
+        }
+        if (d.shader != 0 && d.off_nrm >= 0) {
+            const float* q = reinterpret_cast<const float*>(rec + d.off_nrm);
+            nrm[0] = load_f32(q); nrm[1] = load_f32(q + 1); nrm[2] = load_f32(q + 2);
+        }
+    }
     float m[16], nm[9], mine;
     wave_matrices(up, d, m, nm, mine);
     if (c.first == 0 && lane_id() < 16u) fp.derived[c.draw].clip_m[lane_id()] = mine;
-    uint32_t v = c.first + lane_id();
-    if (v >= d.vert_count) return;
+    if (!live) return;
+    /* vertex shader position: M * vec4(pos,1), then the reference's clip-space y = 1 - y
+     * (test_ktx.vert:28-29, push_constants.vert:28-29, dummy.vert.glsl:22-23) */
     float clip[4];
-    vs_position(d, m, v, clip);
+    mat4_point(m, pos[0], pos[1], pos[2], clip);
+    clip[1] = 1.0f - clip[1];
     uint32_t oc = outcode(clip[0], clip[1], clip[2], clip[3]);
     SVtx out;
     if (oc & (OC_ZNEG | OC_ZPOS | OC_GUARD | OC_INVALID)) {
@@ -233,17 +253,8 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     fp.svtx[d.svtx_base + v] = out;
     /* the rest of the vertex shader: v_normal (test_ktx.vert:30, push_constants.vert:30) and v_uv */
     SVary vo;
-    vo.nx = vo.ny = vo.nz = 0.0f; vo.u = vo.v = 0.0f; vo.pad[0] = vo.pad[1] = vo.pad[2] = 0.0f;
-    if (d.off_uv >= 0) {
-        const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_uv);
-        vo.u = load_f32(p); vo.v = load_f32(p + 1);
-    }
+    vo.nx = vo.ny = vo.nz = 0.0f; vo.u = uv[0]; vo.v = uv[1]; vo.pad[0] = vo.pad[1] = vo.pad[2] = 0.0f;
     if (d.shader != 0) {
-        float nrm[3] = {0.0f, 0.0f, 0.0f};
-        if (d.off_nrm >= 0) {
-            const float* p = reinterpret_cast<const float*>(d.vb + (size_t)v * d.stride + d.off_nrm);
-            nrm[0] = load_f32(p); nrm[1] = load_f32(p + 1); nrm[2] = load_f32(p + 2);
-        }
         const float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
         const float len = sqrtf(len2);
         const float nn[3] = {nrm[0] / len, nrm[1] / len, nrm[2] / len};
