@@ -266,6 +266,48 @@ def test_frames_in_flight_keep_their_uniforms(device, oracle, images):
         assert np.array_equal(got[img][0], oc), "image %d (frame %d): colour differs" % (img, frame)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_seeded_scene_sweep(device, oracle, seed):
+    """A sweep over the knobs together: target size (odd sizes, partial tiles), triangle count and
+    extent (pixel-sized to screen-filling), depth range across both planes, exact depth ties, draw
+    count, shader, texture, cull state, compare op, sample count."""
+    rng = np.random.RandomState(1000 + seed)
+    w, h = int(rng.randint(33, 400)), int(rng.randint(17, 300))
+    shader = [scenes.SHADER_PUSH_CONSTANTS, scenes.SHADER_TEST_KTX, scenes.SHADER_DUMMY][seed % 3]
+    texture = None if shader == scenes.SHADER_PUSH_CONSTANTS else tex(int(rng.choice([16, 40, 128])), seed, tiled=bool(seed & 1),
+                                                                       filtering=int(rng.randint(0, 2)))
+    kw = dict(cull_mode=int(rng.randint(0, 4)), front_face=int(rng.randint(0, 2)), depth_compare=int(rng.choice([1, 3])))
+    sc = helpers.soup_scene(w, h, int(rng.choice([40, 700, 6000])), seed, max_extent=float(rng.choice([0.02, 0.3, 2.5])),
+                            depth_levels=int(rng.choice([0, 0, 3])), z_range=[(0.05, 0.95), (-0.3, 1.3)][seed & 1],
+                            shader=shader, n_draws=int(rng.randint(1, 9)), texture=texture, samples=int(rng.choice([1, 4])),
+                            pipeline_kw=kw)
+    check(sc, device, oracle)
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_mixed_state_pass(device, oracle, samples):
+    """One pass whose draws differ in shader, texture, sampler, cull state and uniform buffer: the
+    per-draw path of shading (nothing is uniform over the pass), with clipping and depth ties."""
+    sc = helpers.soup_scene(224, 160, 1800, 31, n_draws=12, depth_levels=4, z_range=(-0.2, 1.2), samples=samples)
+    rng = np.random.RandomState(5)
+    sc.textures.append(tex(64, 3))
+    sc.textures.append(dict(texels=scenes.checker_texture(48, 9), gen_mips=False, filtering=0, tiled=True, fmt=37))
+    sc.pipelines = [scenes.default_pipeline(scenes.SHADER_PUSH_CONSTANTS, samples, cull_mode=0),
+                    scenes.default_pipeline(scenes.SHADER_TEST_KTX, samples, cull_mode=2),
+                    scenes.default_pipeline(scenes.SHADER_DUMMY, samples, cull_mode=1),
+                    scenes.default_pipeline(scenes.SHADER_TEST_KTX, samples, cull_mode=0, front_face=1)]
+    second = np.array(sc.ubos[0], dtype=np.float32).copy()
+    second[64:80] = hm.scale(hm.identity(), [0.8, 1.1, 1.0]).reshape(16)  # another mvp for some draws
+    sc.ubos.append(second)
+    for k, d in enumerate(sc.draws):
+        d["pipeline"] = k % 4
+        d["texture"] = [-1, 0, 1, 1][k % 4] if k % 8 < 4 else [-1, 1, 0, 0][k % 4]
+        d["ubo"] = k % 2
+        m = hm.translate(hm.identity(), [0.05 * rng.randn(), 0.05 * rng.randn(), 0.0])
+        d["push"] = scenes.push_block([rng.rand(), rng.rand(), rng.rand(), 1.0], m)
+    check(sc, device, oracle)
+
+
 def test_uniform_write_paths(device, oracle):
     """The small uniform write is held back and travels with the submits; everything else that
     touches the buffer must still see it: a read-back, a write to another range (which stores the
