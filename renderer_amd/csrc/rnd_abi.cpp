@@ -392,11 +392,11 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         if (e != hipSuccess) { delete dev; return fail(RND_ERROR_DEVICE_LOST, "hipStreamCreate failed"); }
         dev->own_stream = true;
     }
-    /* sRGB tables: decode[k] = linear value of code k; thr[k] = linear value of code k-0.5;
+    /* texel tables: value[0][k] = linear value of sRGB code k, value[1][k] = k / 255; thr[k] = linear value of code k-0.5;
      * lut[bucket] = number of thresholds <= the bucket's lower edge */
     ShadeTables& host_tables = dev->host_tables;
     memset(&host_tables, 0, sizeof(host_tables));
-    for (int k = 0; k < 256; ++k) host_tables.decode[k] = (float)srgb_to_linear(k / 255.0);
+    for (int k = 0; k < 256; ++k) { host_tables.value[0][k] = (float)srgb_to_linear(k / 255.0); host_tables.value[1][k] = (float)k / 255.0f; }
     host_tables.thr[0] = -INFINITY;
     for (int k = 1; k < 256; ++k) host_tables.thr[k] = (float)srgb_to_linear((k - 0.5) / 255.0);
     host_tables.thr[256] = INFINITY;
@@ -1138,7 +1138,11 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     if (int r = set_device(dev)) return r;
     FrameParams fp = cmd->fp;
     fp.shard_index = cmd->shard_index; fp.shard_count = cmd->shard_count;
+#ifdef RND_PROBES
     { const char* dbg = getenv("RND_DEBUG"); fp.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u; }
+#else
+    fp.debug_flags = 0u;
+#endif
     hipStream_t s = cmd->stream;
     rnd_target tg = cmd->target;
     if (s != dev->stream && dev->stream_dirty) {

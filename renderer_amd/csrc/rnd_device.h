@@ -30,6 +30,20 @@ __device__ __forceinline__ float load_f32(const float* p) { return *(GlobalF32)p
 __device__ __forceinline__ uint32_t load_u32(const uint32_t* p) { return *(GlobalU32)p; }
 __device__ __forceinline__ bool finite32(float v) { return fabsf(v) <= 3.4028234663852886e38f; }
 
+/* 1.0f / x, rounded as the division rounds it, in half the instructions.  The hardware's estimate
+ * refined by one Newton step in fused multiply-adds equals the IEEE quotient for every x whose
+ * magnitude is a normal number below 2^126: tools/micro/rcp_exact.hip compares the two over all 2^32
+ * bit patterns.  Zero, subnormals, the top two binades, infinities and NaN take the division. */
+__device__ __forceinline__ float recip32(float x)
+{
+    const float ax = fabsf(x);
+    if (ax >= 1.17549435082228750797e-38f && ax < 8.50705917302346158658e37f) {
+        const float r = __builtin_amdgcn_rcpf(x);
+        return fma32(fma32(-x, r, 1.0f), r, r);
+    }
+    return 1.0f / x;
+}
+
 /* window coordinate -> 24.8: floor(fma(v, 256, 0.5)) */
 __device__ __forceinline__ int32_t snap(float v)
 {
@@ -172,7 +186,7 @@ struct Projected {
 __device__ __forceinline__ Projected project(const FrameParams& fp, float x, float y, float z, float w)
 {
     Projected p;
-    float iw = 1.0f / w;
+    float iw = recip32(w);
     float xd = x * iw, yd = y * iw, zd = z * iw;
     p.x = snap(fma32(xd, fp.half_w, fp.ox));
     p.y = snap(fma32(yd, fp.half_h, fp.oy));
@@ -231,7 +245,7 @@ __device__ __forceinline__ bool setup_tri(RTri& t, uint32_t cull_mode, uint32_t 
         s = -s;
     }
     t.area2 = s;
-    t.inv_area = 1.0f / (float)s;
+    t.inv_area = recip32((float)s);
     return true;
 }
 

@@ -37,11 +37,11 @@ constexpr uint32_t SRGB_LUT_FIRST = 0x39000000u >> 16; /* 2^-13 */
 constexpr uint32_t SRGB_LUT_LAST = 0x3F800000u >> 16;  /* 1.0 */
 constexpr uint32_t SRGB_LUT_SIZE = SRGB_LUT_LAST - SRGB_LUT_FIRST;
 
-/* sRGB tables, staged in LDS by the kernels that shade: decode[k] = linear value of code k;
- * thr[k] = linear value of code k-0.5 (thr[0] = -inf, thr[256] = +inf); lut[bucket] = number of
- * thresholds not above the bucket's lower edge */
+/* Texel tables, staged in LDS by the kernels that shade: value[0][k] = linear value of sRGB code k,
+ * value[1][k] = float(k) / 255 (a UNORM channel); thr[k] = linear value of sRGB code k-0.5
+ * (thr[0] = -inf, thr[256] = +inf); lut[bucket] = number of thresholds not above the bucket's lower edge */
 struct __attribute__((aligned(16))) ShadeTables {
-    float decode[256];
+    float value[2][256];
     float thr[257];
     uint8_t lut[SRGB_LUT_SIZE];
     uint8_t pad[12]; /* size is a multiple of 16 bytes */
@@ -157,6 +157,14 @@ struct IndexRangeJob {
 };
 
 /* Everything a frame's kernels need; passed by value as the kernel argument */
+/* Probe masks switch parts of a kernel off to time the rest; the frame is then wrong.  They exist
+ * only in a build with -DRND_PROBES (tools/build_variant.sh), which reads the mask from RND_DEBUG. */
+#ifdef RND_PROBES
+#define RND_PROBE(fp, bit) (((fp).debug_flags & (bit)) != 0u)
+#else
+#define RND_PROBE(fp, bit) false
+#endif
+
 struct FrameParams {
     const DrawStatic* draws;
     DrawDerived* derived;
@@ -197,7 +205,7 @@ struct FrameParams {
     int32_t pass_shader;     /* shader of every draw of the pass, or -1 when they differ */
     int32_t pass_texture;    /* texture index of every draw (-1: none bound), or -2 when they differ */
     TexDesc pass_tex;        /* textures[pass_texture] by value */
-    uint32_t debug_flags;    /* timing experiments only: 1 skip shading, 2 skip rasterisation */
+    uint32_t debug_flags;    /* probe masks of a build with RND_PROBES (timing experiments; results are wrong); otherwise unused */
 };
 
 

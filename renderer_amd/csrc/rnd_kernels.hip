@@ -421,8 +421,8 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
     PrimFetch pf;
     pf.idx[0] = pf.idx[1] = pf.idx[2] = 0;
     if (tri < d.tri_count && fetch_prim(fp, d, tri, pf)) {
-        const int cls = (fp.debug_flags & 4u) ? 0 : classify_prim(pf);
-        if (fp.debug_flags & 4u) { if (pf.oc_any == 0xFFFFu) fp.prim_rec[slot].v0 = 1; }
+        const int cls = RND_PROBE(fp, 4u) ? 0 : classify_prim(pf);
+        if (RND_PROBE(fp, 4u)) { if (pf.oc_any == 0xFFFFu) fp.prim_rec[slot].v0 = 1; }
         if (cls == 2) {
             needs_clip = true;
         } else if (cls == 1) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
             }
         }
     }
-    if (!(fp.debug_flags & 8u)) bin_wave(fp, valid, e, box);
+    if (!RND_PROBE(fp, 8u)) bin_wave(fp, valid, e, box);
 
     /* Primitives that cross the near plane, the far plane or the guard band (rare): the wave clips
      * them CLIP_LANES at a time, lane j taking the j-th of them, with the polygons in LDS. */
@@ -511,7 +511,7 @@ struct EdgeSetup {
         bias1 = owns_edge(t.x[2], t.y[2], t.x[0], t.y[0]) ? 0 : 1;
         bias2 = owns_edge(t.x[0], t.y[0], t.x[1], t.y[1]) ? 0 : 1;
         const I area2 = edge_mul(dx2, (I)t.y[2] - (I)t.y[0]) - edge_mul(dy2, (I)t.x[2] - (I)t.x[0]);
-        inv_area = 1.0f / (float)area2;
+        inv_area = recip32((float)area2);
         z0 = t.z[0]; dz1 = t.z[1] - t.z[0]; dz2 = t.z[2] - t.z[0];
         const uint32_t ord = fp.depth_less ? t.slot : ~t.slot;
         payload = ((unsigned long long)ord << 8) | (unsigned long long)t.payload_lo;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
     const bool hit = have && tri_box_in_tile(fp, tc, t, x0, y0, x1, y1);
     const int area = hit ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
     const bool small = tri_is_small(t);
-    if (fp.debug_flags & 128u) { if (hit && t.z[0] == 123.0f) tc.keys[0] = 0; return; }
+    if (RND_PROBE(fp, 128u)) { if (hit && t.z[0] == 123.0f) tc.keys[0] = 0; return; }
     if (__ballot(hit && small && area > DIRECT_PIXELS)) raster_chunks<S>(fp, tc, hit && small, t, x0, y0, x1, y1);
     else if (hit && small) raster_lane<S>(fp, tc, t, x0, y0, x1, y1);
     /* too large for 32-bit edge products: one at a time by the whole wave (ballot, broadcast, 8x8 blocks) */
@@ -770,95 +770,177 @@ __device__ __forceinline__ int wrap_coord(int i, int n, uint32_t tiled)
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-/* texel (x, y) of a level whose row `y` starts `row` texels into it */
-__device__ __forceinline__ void fetch_texel(const ShadeTables& tb, const TexDesc& t, const uint8_t* lv, uint32_t row, int x, float* rgb)
+/* i and i + 1 wrapped into [0, n): what wrap_coord returns for each, with one remainder instead of
+ * two (a mask when the texture's sizes are powers of two, so every level's are) */
+__device__ __forceinline__ void wrap_pair(int i, int n, bool tiled, bool pow2, int& a, int& b)
 {
-    /* a level holds at most 16384 x 16384 texels: the byte offset fits 32 bits.  Texels live in
-     * device memory: say so, or a pointer read from a descriptor costs a flat load */
-    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexel;
-    const uint32_t p = *(GlobalTexel)(lv + ((row + (uint32_t)x) << 2));
-    const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u;
-    if (t.srgb) { rgb[0] = tb.decode[r]; rgb[1] = tb.decode[g]; rgb[2] = tb.decode[b]; }
-    else { rgb[0] = (float)r / 255.0f; rgb[1] = (float)g / 255.0f; rgb[2] = (float)b / 255.0f; }
+    if (tiled) {
+        if (pow2) a = i & (n - 1);
+        else { const int m = i % n; a = m < 0 ? m + n : m; }
+        b = a + 1 == n ? 0 : a + 1;
+    } else {
+        a = min(max(i, 0), n - 1);
+        b = min(max(i + 1, 0), n - 1);
+    }
+}
+
+__device__ __forceinline__ int wrap_one(int i, int n, bool tiled, bool pow2)
+{
+    if (tiled) {
+        if (pow2) return i & (n - 1);
+        const int m = i % n;
+        return m < 0 ? m + n : m;
+    }
+    return min(max(i, 0), n - 1);
 }
 
 /* pointer into LDS, typed as such so a per-lane index compiles to a ds_read and not a flat load */
 typedef const __attribute__((address_space(3))) unsigned long long* LdsLevels;
 
-/* one level at (u, v), both finite */
-template <bool PASS_TEX>
-__device__ void sample_level(const ShadeTables& tb, const TexDesc& t, LdsLevels lds_levels, uint32_t level, float u, float v, float* rgb)
+/* What a sampler needs of a texture, in registers: scalar for the pass-wide texture, per lane otherwise */
+struct TexView {
+    uint32_t width, height, levels;
+    bool tiled, linear, pow2;
+    uint32_t table; /* which half of ShadeTables::value decodes its texels */
+};
+
+__device__ __forceinline__ TexView view_of(const TexDesc& t)
 {
-    int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
-    /* the level differs from lane to lane: its base comes from the copy of the pass texture's
-     * table in LDS when there is one, else from the descriptor in memory */
-    const uint8_t* lv;
-    if constexpr (PASS_TEX) lv = reinterpret_cast<const uint8_t*>(lds_levels[level]);
-    else lv = t.level[level];
-    if (t.filter_linear) {
-        float fu = fma32(u, (float)w, -0.5f), fv = fma32(v, (float)h, -0.5f);
-        fu = fminf(fmaxf(fu, -1.0e9f), 1.0e9f);
-        fv = fminf(fmaxf(fv, -1.0e9f), 1.0e9f);
-        float iu = floorf(fu), iv = floorf(fv);
-        float ax = fu - iu, ay = fv - iv;
-        int x0 = wrap_coord((int)iu, w, t.tiled), x1 = wrap_coord((int)iu + 1, w, t.tiled);
-        int y0 = wrap_coord((int)iv, h, t.tiled), y1 = wrap_coord((int)iv + 1, h, t.tiled);
-        const uint32_t row0 = __umul24((uint32_t)y0, (uint32_t)w), row1 = __umul24((uint32_t)y1, (uint32_t)w);
-        float c00[3], c10[3], c01[3], c11[3];
-        fetch_texel(tb, t, lv, row0, x0, c00);
-        fetch_texel(tb, t, lv, row0, x1, c10);
-        fetch_texel(tb, t, lv, row1, x0, c01);
-        fetch_texel(tb, t, lv, row1, x1, c11);
+    TexView tv;
+    tv.width = t.width; tv.height = t.height; tv.levels = t.levels;
+    tv.tiled = t.tiled != 0u; tv.linear = t.filter_linear != 0u;
+    tv.pow2 = ((t.width & (t.width - 1u)) | (t.height & (t.height - 1u))) == 0u;
+    tv.table = t.srgb ? 0u : 1u;
+    return tv;
+}
+
+/* The level differs from lane to lane: its base comes from the copy of the pass texture's table in
+ * LDS when there is one, else from the descriptor in memory */
+template <bool PASS_TEX>
+__device__ __forceinline__ const uint8_t* level_base(const TexDesc& t, LdsLevels lds_levels, uint32_t level)
+{
+    if constexpr (PASS_TEX) return reinterpret_cast<const uint8_t*>(lds_levels[level]);
+    else return t.level[level];
+}
+
+/* A level holds at most 16384 x 16384 texels, so a texel's byte offset fits 32 bits.  Texels live
+ * in device memory: say so, or a pointer read from a descriptor costs a flat load. */
+__device__ __forceinline__ uint32_t load_texel(const uint8_t* lv, uint32_t byte_offset)
+{
+    typedef const __attribute__((address_space(1))) uint32_t* GlobalTexel;
+    return *(GlobalTexel)(lv + byte_offset);
+}
+
+__device__ __forceinline__ void decode_texel(const ShadeTables& tb, uint32_t table, uint32_t p, float* rgb)
+{
+    const float* value = tb.value[table];
+    rgb[0] = value[p & 255u]; rgb[1] = value[(p >> 8) & 255u]; rgb[2] = value[(p >> 16) & 255u];
+}
+
+/* The four texels a bilinear sample of one level reads, as byte offsets into the level
+ * ((x0,y0) (x1,y0) (x0,y1) (x1,y1)), and its two blend fractions.  Offsets first, loads next,
+ * arithmetic last: the loads of a sample (eight for a trilinear one) are then in flight together
+ * instead of each waiting for the one before it. */
+struct Taps {
+    uint32_t off[4];
+    float ax, ay;
+};
+
+__device__ __forceinline__ void linear_taps(const TexView& t, uint32_t level, float u, float v, Taps& tp)
+{
+    const int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
+    float fu = fma32(u, (float)w, -0.5f), fv = fma32(v, (float)h, -0.5f);
+    fu = fminf(fmaxf(fu, -1.0e9f), 1.0e9f);
+    fv = fminf(fmaxf(fv, -1.0e9f), 1.0e9f);
+    const float iu = floorf(fu), iv = floorf(fv);
+    tp.ax = fu - iu; tp.ay = fv - iv;
+    int x0, x1, y0, y1;
+    wrap_pair((int)iu, w, t.tiled, t.pow2, x0, x1);
+    wrap_pair((int)iv, h, t.tiled, t.pow2, y0, y1);
+    const uint32_t row0 = __umul24((uint32_t)y0, (uint32_t)w), row1 = __umul24((uint32_t)y1, (uint32_t)w);
+    tp.off[0] = (row0 + (uint32_t)x0) << 2; tp.off[1] = (row0 + (uint32_t)x1) << 2;
+    tp.off[2] = (row1 + (uint32_t)x0) << 2; tp.off[3] = (row1 + (uint32_t)x1) << 2;
+}
+
+__device__ __forceinline__ uint32_t nearest_tap(const TexView& t, uint32_t level, float u, float v)
+{
+    const int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
+    const float fu = fminf(fmaxf(u * (float)w, -1.0e9f), 1.0e9f);
+    const float fv = fminf(fmaxf(v * (float)h, -1.0e9f), 1.0e9f);
+    const int x = wrap_one((int)floorf(fu), w, t.tiled, t.pow2), y = wrap_one((int)floorf(fv), h, t.tiled, t.pow2);
+    return (__umul24((uint32_t)y, (uint32_t)w) + (uint32_t)x) << 2;
+}
+
+__device__ __forceinline__ void bilinear(const ShadeTables& tb, uint32_t table, const uint32_t* p, float ax, float ay, float* rgb)
+{
+    float c00[3], c10[3], c01[3], c11[3];
+    decode_texel(tb, table, p[0], c00);
+    decode_texel(tb, table, p[1], c10);
+    decode_texel(tb, table, p[2], c01);
+    decode_texel(tb, table, p[3], c11);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float top = fma32(ax, c10[k] - c00[k], c00[k]);
-            float bot = fma32(ax, c11[k] - c01[k], c01[k]);
-            rgb[k] = fma32(ay, bot - top, top);
-        }
-    } else {
-        float fu = fminf(fmaxf(u * (float)w, -1.0e9f), 1.0e9f);
-        float fv = fminf(fmaxf(v * (float)h, -1.0e9f), 1.0e9f);
-        int x = wrap_coord((int)floorf(fu), w, t.tiled), y = wrap_coord((int)floorf(fv), h, t.tiled);
-        fetch_texel(tb, t, lv, __umul24((uint32_t)y, (uint32_t)w), x, rgb);
+    for (int k = 0; k < 3; ++k) {
+        const float top = fma32(ax, c10[k] - c00[k], c00[k]);
+        const float bot = fma32(ax, c11[k] - c01[k], c01[k]);
+        rgb[k] = fma32(ay, bot - top, top);
     }
 }
 
 /* texture() with implicit derivatives: lod = log2(longest footprint axis), clamped to
  * [0, levels-1], trilinear (sampler of tools.cpp:60-82) */
 template <bool PASS_TEX>
-__device__ void sample_texture(const ShadeTables& tb, const TexDesc& t, LdsLevels lds_levels, float u, float v,
-                               float dudx, float dvdx, float dudy, float dvdy, float* rgb)
+__device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexDesc& desc, LdsLevels lds_levels, float u, float v,
+                                               float dudx, float dvdx, float dudy, float dvdy, float* rgb)
 {
-    float w0 = (float)t.width, h0 = (float)t.height;
-    float mxu = dudx * w0, mxv = dvdx * h0, myu = dudy * w0, myv = dvdy * h0;
-    float rx = fma32(mxv, mxv, mxu * mxu), ry = fma32(myv, myv, myu * myu);
+    const TexView t = view_of(desc);
+    const float w0 = (float)t.width, h0 = (float)t.height;
+    const float mxu = dudx * w0, mxv = dvdx * h0, myu = dudy * w0, myv = dvdy * h0;
+    const float rx = fma32(mxv, mxv, mxu * mxu), ry = fma32(myv, myv, myu * myu);
     float lambda = 0.5f * lod_log2(fmaxf(rx, ry));
-    float max_lod = (float)(t.levels - 1);
+    const float max_lod = (float)(t.levels - 1);
     lambda = fminf(fmaxf(lambda, 0.0f), max_lod);
     if (!finite32(u)) u = 0.0f;
     if (!finite32(v)) v = 0.0f;
     const bool base_only = !(lambda > 0.0f) || t.levels == 1; /* magnified: level 0 alone */
-    if (!__ballot(!base_only)) { sample_level<PASS_TEX>(tb, t, lds_levels, 0, u, v, rgb); return; }
-    if (t.filter_linear) {
-        /* Lanes of one wave usually disagree about base_only.  Rather than run the one-level and
-         * the two-level code one after the other, every lane blends two levels; a base-only lane
-         * blends level 0 with itself at fraction 0, which returns the level-0 sample unchanged. */
-        const float fl = base_only ? 0.0f : floorf(lambda);
-        const uint32_t lo = (uint32_t)fl;
-        const uint32_t hi = base_only ? 0u : (lo + 1 < t.levels ? lo + 1 : t.levels - 1);
-        const float frac = base_only ? 0.0f : lambda - fl;
-        float a[3], b[3];
-        sample_level<PASS_TEX>(tb, t, lds_levels, lo, u, v, a);
-        sample_level<PASS_TEX>(tb, t, lds_levels, hi, u, v, b);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) rgb[k] = fma32(frac, b[k] - a[k], a[k]);
-    } else if (base_only) {
-        sample_level<PASS_TEX>(tb, t, lds_levels, 0, u, v, rgb);
-    } else {
-        float lv = ceilf(lambda + 0.5f) - 1.0f;
-        lv = fminf(fmaxf(lv, 0.0f), max_lod);
-        sample_level<PASS_TEX>(tb, t, lds_levels, (uint32_t)lv, u, v, rgb);
+    if (!t.linear) {
+        uint32_t level = 0;
+        if (!base_only) level = (uint32_t)fminf(fmaxf(ceilf(lambda + 0.5f) - 1.0f, 0.0f), max_lod);
+        const uint32_t p = load_texel(level_base<PASS_TEX>(desc, lds_levels, level), nearest_tap(t, level, u, v));
+        decode_texel(tb, t.table, p, rgb);
+        return;
     }
+    if (!__ballot(!base_only)) {
+        Taps tp;
+        linear_taps(t, 0, u, v, tp);
+        const uint8_t* lv = level_base<PASS_TEX>(desc, lds_levels, 0);
+        uint32_t p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = load_texel(lv, tp.off[k]);
+        bilinear(tb, t.table, p, tp.ax, tp.ay, rgb);
+        return;
+    }
+    /* Lanes of one wave usually disagree about base_only.  Rather than run the one-level and the
+     * two-level code one after the other, every lane blends two levels; a base-only lane blends
+     * level 0 with itself at fraction 0, which returns the level-0 sample unchanged. */
+    const float fl = base_only ? 0.0f : floorf(lambda);
+    const uint32_t lo = (uint32_t)fl;
+    const uint32_t hi = base_only ? 0u : (lo + 1 < t.levels ? lo + 1 : t.levels - 1);
+    const float frac = base_only ? 0.0f : lambda - fl;
+    Taps ta, tc;
+    linear_taps(t, lo, u, v, ta);
+    linear_taps(t, hi, u, v, tc);
+    const uint8_t* la = level_base<PASS_TEX>(desc, lds_levels, lo);
+    const uint8_t* lc = level_base<PASS_TEX>(desc, lds_levels, hi);
+    uint32_t pa[4], pc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pa[k] = load_texel(la, ta.off[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pc[k] = load_texel(lc, tc.off[k]);
+    float a[3], c[3];
+    bilinear(tb, t.table, pa, ta.ax, ta.ay, a);
+    bilinear(tb, t.table, pc, tc.ax, tc.ay, c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = fma32(frac, c[k] - a[k], a[k]);
 }
 
 /* Perspective-correct weights of a fragment over the three corners of its triangle, at the pixel
@@ -888,7 +970,7 @@ __device__ __forceinline__ void weights_at(const EdgeFloats& t, float e0, float 
     const float p1 = (e1 * t.inv_s) * t.iw[1];
     const float p2 = (e2 * t.inv_s) * t.iw[2];
     const float den = (p0 + (t.swapped ? p2 : p1)) + (t.swapped ? p1 : p2);
-    const float rden = 1.0f / den;
+    const float rden = recip32(den);
     q[0] = p0 * rden; q[1] = p1 * rden; q[2] = p2 * rden;
 }
 
@@ -932,7 +1014,7 @@ __device__ __forceinline__ void corner_weights(const Corners& c, int x, int y, b
     }
     EdgeFloats t;
     t.swapped = fs < 0.0f;
-    t.inv_s = 1.0f / fs;
+    t.inv_s = recip32(fs);
     t.iw[0] = c.iw[0]; t.iw[1] = c.iw[1]; t.iw[2] = c.iw[2];
     weights_at(t, fe[0], fe[1], fe[2], q);
     if (want_derivs) {
@@ -1118,11 +1200,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp, uint32_t 
     for (uint32_t i = threadIdx.x; i < TILE_PIXELS * S; i += TILE_THREADS) keys[i] = clear_key;
     __syncthreads();
 
-    if (tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1 && !(fp.debug_flags & 2u)) {
+    if (tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1 && !RND_PROBE(fp, 2u)) {
         /* this tile's list: 16-byte entries, one per lane per batch */
         uint32_t count = min(fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE], fp.tile_capacity);
-        if (fp.debug_flags & 16u) count = min(count, 256u);
-        if (fp.debug_flags & 64u) count = min(count, 512u);
+        if (RND_PROBE(fp, 16u)) count = min(count, 256u);
+        if (RND_PROBE(fp, 64u)) count = min(count, 512u);
         const TileEntry* list = fp.tile_lists + (size_t)tile * fp.tile_stride;
         raster_stream<S>(fp, tc, count, [&](uint32_t i, TileEntry& e) -> bool { e = list[i]; return true; });
         /* the pass-wide list: primitives spanning many tiles, and spill of full tile lists */
@@ -1171,25 +1253,32 @@ __global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(Frame
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
     /* the frame's list counters were last read by the tile kernel: clear them for the next frame */
     if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
-    stage_tables(tb, fp.tables);
-    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
-    __syncthreads();
     uint32_t bx, by;
     rows_of_eight(blockIdx.x, blocks_x, magic, bx, by);
     const int x = (int)(bx * 32u + (threadIdx.x & 31u)), y = (int)(by * 8u + (threadIdx.x >> 5));
-    if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) return;
-    if (fp.shard_count > 1) {
+    bool mine = !(x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1);
+    if (mine && fp.shard_count > 1) {
         const uint32_t tile = (uint32_t)(y >> TILE_SHIFT) * fp.tiles_x + (uint32_t)(x >> TILE_SHIFT);
-        if (tile % fp.shard_count != fp.shard_index) return;
+        mine = tile % fp.shard_count == fp.shard_index;
     }
+    /* the pixel's owners are asked for before the tables are staged: the two round trips to memory
+     * overlap instead of following one another */
     const size_t pi = (size_t)y * fp.width + (size_t)x;
     uint32_t vis[S];
-    if constexpr (S == 4) {
-        const uint4 v4 = reinterpret_cast<const uint4*>(fp.vis)[pi];
-        vis[0] = v4.x; vis[1] = v4.y; vis[2] = v4.z; vis[3] = v4.w;
-    } else {
-        vis[0] = fp.vis[pi];
+#pragma unroll
+    for (int s = 0; s < S; ++s) vis[s] = VIS_NONE;
+    if (mine) {
+        if constexpr (S == 4) {
+            const uint4 v4 = reinterpret_cast<const uint4*>(fp.vis)[pi];
+            vis[0] = v4.x; vis[1] = v4.y; vis[2] = v4.z; vis[3] = v4.w;
+        } else {
+            vis[0] = fp.vis[pi];
+        }
     }
+    stage_tables(tb, fp.tables);
+    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
+    __syncthreads();
+    if (!mine) return;
     /* no fragment landed on the pixel: the clear colour, encoded once on the host */
     bool untouched = true;
 #pragma unroll
@@ -1205,7 +1294,7 @@ __global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(Frame
             smp[s][0] = smp[reuse][0]; smp[s][1] = smp[reuse][1]; smp[s][2] = smp[reuse][2]; smp[s][3] = smp[reuse][3];
         } else if (vis[s] == VIS_NONE) {
             smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
-        } else if (fp.debug_flags & 1u) {
+        } else if (RND_PROBE(fp, 1u)) {
             smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.5f;
         } else {
             shade_pixel(fp, tb, (LdsLevels)pass_levels, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, (vis[s] & FLAG_CLIPPED) != 0u, x, y, smp[s]);
@@ -1247,10 +1336,10 @@ __global__ __launch_bounds__(256) void k_mip(const uint8_t* src, uint32_t sw, ui
         for (int k = 0; k < 4; ++k) {
             bool lin = !(srgb && k < 3);
             uint32_t b00 = (p00 >> (8 * k)) & 255u, b10 = (p10 >> (8 * k)) & 255u, b01 = (p01 >> (8 * k)) & 255u, b11 = (p11 >> (8 * k)) & 255u;
-            float c00 = lin ? (float)b00 / 255.0f : tb.decode[b00];
-            float c10 = lin ? (float)b10 / 255.0f : tb.decode[b10];
-            float c01 = lin ? (float)b01 / 255.0f : tb.decode[b01];
-            float c11 = lin ? (float)b11 / 255.0f : tb.decode[b11];
+            float c00 = tb.value[lin][b00];
+            float c10 = tb.value[lin][b10];
+            float c01 = tb.value[lin][b01];
+            float c11 = tb.value[lin][b11];
             float top = fma32(ax, c10 - c00, c00);
             float bot = fma32(ax, c11 - c01, c01);
             float c = fma32(ay, bot - top, top);

@@ -1,5 +1,8 @@
 """Times the stages of one configuration under each RND_DEBUG probe mask (results are wrong
-under a probe; only durations mean anything).  Usage: python tools/probe_flags.py CONFIG MASK [MASK...]"""
+under a probe; only durations mean anything).  Usage: python tools/probe_flags.py CONFIG MASK [MASK...]
+
+The probes exist only in a build with -DRND_PROBES:
+    EXTRA=-DRND_PROBES tools/build_variant.sh probes && RENDERER_AMD_LIB=build/lib_probes.so python tools/probe_flags.py 1 0 1 2"""
 import os, subprocess, sys, json
 cfg = sys.argv[1]
 for m in sys.argv[2:]:

@@ -1,5 +1,6 @@
 #!/bin/bash
 # VALU instruction count and duration of the frame's kernels under RND_DEBUG probe masks (GPU box).
+# Needs a library built with -DRND_PROBES (EXTRA=-DRND_PROBES tools/build_variant.sh probes) named by RENDERER_AMD_LIB.
 export TMPDIR=/tmp
 for m in "$@"; do
   OUT=gpurun_out/valu_$m; mkdir -p $OUT
