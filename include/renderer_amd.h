@@ -106,7 +106,7 @@ typedef struct rnd_pipeline_info {
 } rnd_pipeline_info;
 
 /* Stage times of the most recent profiled submit, in milliseconds. */
-enum { RND_STAGE_VERTEX = 0, RND_STAGE_SETUP, RND_STAGE_TILE, RND_STAGE_SHADE, RND_STAGE_COUNT };
+enum { RND_STAGE_VERTEX = 0, RND_STAGE_SETUP, RND_STAGE_TILE, RND_STAGE_COUNT }; /* TILE: rasterisation and shading, one kernel */
 
 const char* rnd_last_error(void);
 

@@ -30,7 +30,7 @@ FILTER_NEAREST, FILTER_LINEAR = 0, 1
 INDEX_TYPE_UINT32 = 1
 TOPOLOGY_TRIANGLE_LIST = 3
 SHADER_DUMMY, SHADER_TEST_KTX, SHADER_PUSH_CONSTANTS = 0, 1, 2
-STAGE_NAMES = ["vertex", "setup", "tile", "shade"]
+STAGE_NAMES = ["vertex", "setup", "tile"]
 
 
 class RendererError(RuntimeError):

@@ -121,7 +121,6 @@ struct rnd_target_t {
     int32_t color_format;
     uint8_t* color;
     uint32_t* depth;
-    uint32_t* vis; /* owning primitive per sample, handed from the tile kernel to the shading kernel */
     hipEvent_t order_ev;       /* recorded on last_stream when another stream has to wait for it */
     hipStream_t last_stream;   /* stream of the last frame rendered into, or copy taken from, this target */
     bool last_valid;
@@ -642,12 +641,11 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
     if (depth_format != RND_FORMAT_D24_UNORM_S8_UINT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "depth format must be D24_UNORM_S8_UINT");
     if (samples != 1 && samples != 4) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "sample count must be 1 or 4");
     if (int r = set_device(dev)) return r;
-    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, nullptr, nullptr, false};
     if (hipEventCreateWithFlags(&t->order_ev, hipEventDisableTiming) != hipSuccess) { delete t; return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed"); }
     size_t px = (size_t)width * height;
     hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&t->color), px * 4);
     hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&t->depth), px * samples * 4);
-    if (e2 == hipSuccess) e2 = hipMalloc(reinterpret_cast<void**>(&t->vis), px * samples * 4);
     if (e1 != hipSuccess || e2 != hipSuccess) { rnd_target_destroy(t); return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc target failed"); }
     (void)hipMemset(t->color, 0, px * 4);
     (void)hipMemset(t->depth, 0, px * samples * 4);
@@ -691,7 +689,6 @@ int rnd_target_destroy(rnd_target target)
     { auto& list = target->dev->targets; list.erase(std::remove(list.begin(), list.end(), target), list.end()); }
     if (target->color) (void)hipFree(target->color);
     if (target->depth) (void)hipFree(target->depth);
-    if (target->vis) (void)hipFree(target->vis);
     delete target;
     return RND_SUCCESS;
 }
@@ -1067,7 +1064,7 @@ int rnd_cmd_end(rnd_cmd cmd)
         fp.status_host = static_cast<uint32_t*>(dp);
     }
     fp.color = tg->color; fp.depth = tg->depth;
-    fp.vis = tg->vis; fp.tables = dev->tables;
+    fp.tables = dev->tables;
     fp.n_draws = (uint32_t)n; fp.n_vchunks = (uint32_t)vchunks.size(); fp.n_tchunks = (uint32_t)tchunks.size();
     fp.n_textures = (uint32_t)td.size();
     fp.width = tg->width; fp.height = tg->height; fp.samples = tg->samples;
@@ -1159,8 +1156,6 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     launch_setup(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_TILE], s));
     launch_tile(fp, s);
-    if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SHADE], s));
-    launch_shade(fp, s);
     if (prof) { HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_COUNT], s)); dev->stage_valid = true; }
     HIP_TRY(hipGetLastError());
     if (cmd->own_stream) {

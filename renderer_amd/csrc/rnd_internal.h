@@ -185,7 +185,6 @@ struct FrameParams {
                                 (equal low address bits would pile every tile onto the same memory channels) */
     uint8_t* color;          /* resolved colour, width*height*4 */
     uint32_t* depth;         /* width*height*samples */
-    uint32_t* vis;           /* width*height*samples: owning primitive slot | fan index << 28 | clipped << 31, or 0xFFFFFFFF */
     const struct ShadeTables* tables; /* sRGB decode / encode tables */
     uint32_t n_draws, n_vchunks, n_tchunks, n_textures;
     uint32_t width, height, samples;
@@ -214,7 +213,6 @@ void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n
 void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s);
 void launch_setup(const FrameParams& fp, hipStream_t s);
 void launch_tile(const FrameParams& fp, hipStream_t s);
-void launch_shade(const FrameParams& fp, hipStream_t s);
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
                 const struct ShadeTables* tables, hipStream_t s);
 

@@ -1,18 +1,17 @@
 /*
  * rnd_kernels.hip -- gfx950 kernels of the draw path.
  *
- * One submit of a recorded pass runs:
- *   k_constants  per-draw matrices from the uniform buffer (read at execution time,
- *                base_obj_viewer_app.cpp:134-138) and the push constants
- *   k_vertex     vertex fetch + position shader + clip codes + viewport + 24.8 snap
- *   k_setup      per primitive: reject / cull / orient, then append a 16-byte entry to the
- *                list of every tile its box touches (one pass, fixed-capacity lists,
- *                one atomic per wave and tile through ballot + popcount prefix)
- *   k_clip       the few primitives crossing near/far/guard band: clip, fan, bin
- *   k_tile       one workgroup per 32x32 tile: edge-function rasteriser into an LDS
- *                depth/owner word per sample; stores depth and the owning primitive
- *   k_shade      one thread per pixel: one shading per owning primitive, resolve,
- *                sRGB encode, coalesced colour store
+ * One submit of a recorded pass runs three kernels:
+ *   k_vertex     vertex fetch, the draw's matrices built per wave from the uniform buffer as it
+ *                is at execution time (base_obj_viewer_app.cpp:134-138) and the push constants,
+ *                position shader, clip codes, viewport, 24.8 snap
+ *   k_setup      per primitive: reject / cull / orient, then append an entry to the list of
+ *                every tile its box touches (fixed-capacity lists, one atomic per wave and tile
+ *                through ballot + popcount prefix); the few primitives crossing the near / far
+ *                planes or the guard band are clipped here, fanned, and binned
+ *   k_tile       one workgroup per 32x32 tile: edge-function rasteriser into an LDS depth/owner
+ *                word per sample, then per pixel one shading per owning primitive, resolve,
+ *                sRGB encode, coalesced depth and colour stores
  *
  * Depth resolution is order independent: each fragment offers the 64-bit word
  * (D24 << 40 | inverted submission number << 8 | fan index) and the tile keeps the
@@ -208,6 +207,8 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 {
     const FrameParams& fp = args.fp;
     const UniformPatch& up = args.up;
+    /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel */
+    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_vchunks) return;
     const Chunk c = fp.vchunks[chunk];
@@ -1169,15 +1170,62 @@ __device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables*
     for (uint32_t i = threadIdx.x; i < sizeof(ShadeTables) / 16; i += blockDim.x) l[i] = g[i];
 }
 
-constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* sample not covered by any fragment */
+constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* owner word of a sample no fragment covers; otherwise slot | fan << 28 | clipped << 31 */
 
-/* One workgroup per 32x32 tile: rasterise the tile's triangles into one 64-bit word per sample
- * held in LDS (depth, submission order, fan index; the minimum wins), then store the depth
- * words and the winning primitive of every sample with full-row coalesced stores. */
+/* Colour of pixel (x, y), whose samples are owned by vis[0..S): shade each distinct owner once,
+ * resolve, encode, store. */
 template <int S>
-__global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp, uint32_t magic)
+__device__ __forceinline__ void shade_and_store(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
+                                                int x, int y, size_t pi, const uint32_t* vis)
+{
+    /* no fragment landed on the pixel: the clear colour, encoded once on the host */
+    bool untouched = true;
+#pragma unroll
+    for (int s = 0; s < S; ++s) untouched = untouched && vis[s] == VIS_NONE;
+    if (untouched) { reinterpret_cast<uint32_t*>(fp.color)[pi] = fp.clear_packed; return; }
+    float smp[S][4];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int reuse = -1;
+#pragma unroll
+        for (int s2 = 0; s2 < s; ++s2) if (reuse < 0 && vis[s2] == vis[s]) reuse = s2;
+        if (reuse >= 0) {
+            smp[s][0] = smp[reuse][0]; smp[s][1] = smp[reuse][1]; smp[s][2] = smp[reuse][2]; smp[s][3] = smp[reuse][3];
+        } else if (vis[s] == VIS_NONE) {
+            smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
+        } else if (RND_PROBE(fp, 1u)) {
+            smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.5f;
+        } else {
+            shade_pixel(fp, tb, pass_levels, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, (vis[s] & FLAG_CLIPPED) != 0u, x, y, smp[s]);
+        }
+    }
+    float acc[4];
+    if constexpr (S == 1) {
+        acc[0] = smp[0][0]; acc[1] = smp[0][1]; acc[2] = smp[0][2]; acc[3] = smp[0][3];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = ((smp[0][c] + smp[1][c]) + (smp[2][c] + smp[3][c])) * 0.25f;
+    }
+    reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, acc);
+}
+
+/* One workgroup per 32x32 tile, in two phases.  Rasterise the tile's triangles into one 64-bit
+ * word per sample held in LDS (depth, submission order, fan index; the minimum wins).  Then every
+ * thread takes the tile's pixels one row of eight at a time: depth word and owner of each sample
+ * come out of LDS, the owner is shaded (once per distinct fan triangle), the samples are resolved,
+ * encoded and stored; lanes run along x, so depth and colour stores cover whole 128-byte segments.
+ * Workgroups in the two phases share a CU: one's arithmetic fills the other's memory waits. */
+#ifndef TILE_WAVES
+#define TILE_WAVES 5 /* waves per SIMD the single-sample kernel is compiled for (96 VGPRs): the walk wants about 110, and below 5 the spills cost more than the occupancy gains */
+#endif
+template <int S>
+__global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_tile(FrameParams fp, uint32_t magic)
 {
     __shared__ unsigned long long keys[TILE_PIXELS * S];
+    __shared__ ShadeTables tb;
+    __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
+    stage_tables(tb, fp.tables);
+    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
 
     uint32_t tile, utx, uty;
     if (fp.shard_count == 1) {
@@ -1224,90 +1272,23 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(FrameParams fp, uint32_t 
     /* every thread has read the list length: leave the counter clean for the next frame's binning */
     if (threadIdx.x == 0) fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE] = 0;
 
-    /* consecutive lanes take consecutive samples of a row: a wave stores whole 128-byte segments */
-    for (uint32_t q = threadIdx.x; q < TILE_PIXELS * S; q += TILE_THREADS) {
-        const uint32_t p = q / S, s = q % S;
+    for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
         const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
         if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
-        const unsigned long long k = keys[q];
-        const size_t gi = ((size_t)y * fp.width + (size_t)x) * S + s;
-        fp.depth[gi] = fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24;
-        uint32_t vis = VIS_NONE;
-        if (k != clear_key) {
-            const uint32_t low = (uint32_t)(k >> 8);
-            vis = ((fp.depth_less ? low : ~low) & SLOT_MASK) | ((uint32_t)(k & 15ull) << ENTRY_SUB_SHIFT);
+        const size_t pi = (size_t)y * fp.width + (size_t)x;
+        uint32_t vis[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const unsigned long long k = keys[p * S + s];
+            fp.depth[pi * S + s] = fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24;
+            vis[s] = VIS_NONE;
+            if (k != clear_key) {
+                const uint32_t low = (uint32_t)(k >> 8);
+                vis[s] = ((fp.depth_less ? low : ~low) & SLOT_MASK) | ((uint32_t)(k & 15ull) << ENTRY_SUB_SHIFT);
+            }
         }
-        fp.vis[gi] = vis;
+        shade_and_store<S>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);
     }
-}
-
-/* One thread per pixel: shade the primitive that owns each sample (once per distinct fan
- * triangle), resolve, encode, store.  Workgroup = 32x8 pixels, lanes along x. */
-#ifndef SHADE_WAVES
-#define SHADE_WAVES 8 /* waves per SIMD the single-sample shading kernel is compiled for: 64 VGPRs; the few spilled dwords cost less than the lost occupancy */
-#endif
-template <int S>
-__global__ __launch_bounds__(256, (S == 1 ? SHADE_WAVES : 4)) void k_shade(FrameParams fp, uint32_t blocks_x, uint32_t magic)
-{
-    __shared__ ShadeTables tb;
-    __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
-    /* the frame's list counters were last read by the tile kernel: clear them for the next frame */
-    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
-    uint32_t bx, by;
-    rows_of_eight(blockIdx.x, blocks_x, magic, bx, by);
-    const int x = (int)(bx * 32u + (threadIdx.x & 31u)), y = (int)(by * 8u + (threadIdx.x >> 5));
-    bool mine = !(x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1);
-    if (mine && fp.shard_count > 1) {
-        const uint32_t tile = (uint32_t)(y >> TILE_SHIFT) * fp.tiles_x + (uint32_t)(x >> TILE_SHIFT);
-        mine = tile % fp.shard_count == fp.shard_index;
-    }
-    /* the pixel's owners are asked for before the tables are staged: the two round trips to memory
-     * overlap instead of following one another */
-    const size_t pi = (size_t)y * fp.width + (size_t)x;
-    uint32_t vis[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) vis[s] = VIS_NONE;
-    if (mine) {
-        if constexpr (S == 4) {
-            const uint4 v4 = reinterpret_cast<const uint4*>(fp.vis)[pi];
-            vis[0] = v4.x; vis[1] = v4.y; vis[2] = v4.z; vis[3] = v4.w;
-        } else {
-            vis[0] = fp.vis[pi];
-        }
-    }
-    stage_tables(tb, fp.tables);
-    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
-    __syncthreads();
-    if (!mine) return;
-    /* no fragment landed on the pixel: the clear colour, encoded once on the host */
-    bool untouched = true;
-#pragma unroll
-    for (int s = 0; s < S; ++s) untouched = untouched && vis[s] == VIS_NONE;
-    if (untouched) { reinterpret_cast<uint32_t*>(fp.color)[pi] = fp.clear_packed; return; }
-    float smp[S][4];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        int reuse = -1;
-#pragma unroll
-        for (int s2 = 0; s2 < s; ++s2) if (reuse < 0 && vis[s2] == vis[s]) reuse = s2;
-        if (reuse >= 0) {
-            smp[s][0] = smp[reuse][0]; smp[s][1] = smp[reuse][1]; smp[s][2] = smp[reuse][2]; smp[s][3] = smp[reuse][3];
-        } else if (vis[s] == VIS_NONE) {
-            smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
-        } else if (RND_PROBE(fp, 1u)) {
-            smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.5f;
-        } else {
-            shade_pixel(fp, tb, (LdsLevels)pass_levels, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, (vis[s] & FLAG_CLIPPED) != 0u, x, y, smp[s]);
-        }
-    }
-    float acc[4];
-    if constexpr (S == 1) {
-        acc[0] = smp[0][0]; acc[1] = smp[0][1]; acc[2] = smp[0][2]; acc[3] = smp[0][3];
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = ((smp[0][c] + smp[1][c]) + (smp[2][c] + smp[3][c])) * 0.25f;
-    }
-    reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, acc);
 }
 
 /* ------------------------------------------------------------------ mip generation (blit LINEAR, tools.cpp:670-707) */
@@ -1381,15 +1362,6 @@ void launch_tile(const FrameParams& fp, hipStream_t s)
     const uint32_t magic = rows_of_eight_magic(fp.tiles_x);
     if (fp.samples == 4) hipLaunchKernelGGL(k_tile<4>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
     else hipLaunchKernelGGL(k_tile<1>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
-}
-
-void launch_shade(const FrameParams& fp, hipStream_t s)
-{
-    const uint32_t blocks_x = (fp.width + 31) / 32, blocks_y = (fp.height + 7) / 8;
-    const dim3 grid(rows_of_eight_grid(blocks_x, blocks_y));
-    const uint32_t magic = rows_of_eight_magic(blocks_x);
-    if (fp.samples == 4) hipLaunchKernelGGL(k_shade<4>, grid, dim3(256), 0, s, fp, blocks_x, magic);
-    else hipLaunchKernelGGL(k_shade<1>, grid, dim3(256), 0, s, fp, blocks_x, magic);
 }
 
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,

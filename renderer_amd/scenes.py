@@ -73,8 +73,8 @@ class Scene:
     def algorithmic_bytes_by_stage(self):
         """Bytes a frame must move at the least, split by the kernel that moves them: every
         distinct vertex once (vertex), every index once plus one 80-byte constant record per
-        draw (setup), the depth image stored once (tile), the colour image stored once plus one
-        texel per pixel, or the whole texture if smaller (shade)."""
+        draw (setup), the depth image and the colour image stored once each plus one texel per
+        pixel, or the whole texture if smaller (tile: rasterisation and shading are one kernel)."""
         vb = sum(int(v.nbytes) for v in self.vbs)
         ib = sum(int(i.nbytes) for i in self.ibs)
         px = self.width * self.height * 4
@@ -85,7 +85,7 @@ class Scene:
                 h, w = t["texels"].shape[:2]
                 tb += int(w * h * 4 * 4 / 3) if t.get("gen_mips", True) else w * h * 4
             tex = min(px, tb)
-        return {"vertex": vb, "setup": ib + 80 * len(self.draws), "tile": px, "shade": px + tex}
+        return {"vertex": vb, "setup": ib + 80 * len(self.draws), "tile": 2 * px + tex}
 
     def algorithmic_bytes(self):
         """Sum of algorithmic_bytes_by_stage(): the least a whole frame moves."""

@@ -17,7 +17,7 @@ for mode in ("fixed", "orbit"):
         run.submit()
         run.dev.wait_idle()
         st = run.dev.stage_times()
-        ts.append((st["tile"], st["shade"], st["setup"]))
+        ts.append((st["tile"], st["setup"]))
     print(mode, "tile", [round(t[0] * 1e3, 1) for t in ts])
-    print(mode, "shade", [round(t[1] * 1e3, 1) for t in ts])
+    print(mode, "setup", [round(t[1] * 1e3, 1) for t in ts])
 run.destroy()
