@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1)
+    ap.add_argument("--samples", type=int, choices=[1, 4], default=1,
+                    help="samples per pixel (4: what test_app renders with, dummy_obj_viewer_app.cpp:319; resolved in linear light)")
     ap.add_argument("--mode", choices=["views", "tiles"], default="views")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="command buffers / targets the frames rotate through (the reference's swapchain image count)")
@@ -123,6 +125,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     scene = build_scene(args.config)
+    if args.samples != 1:
+        scene.samples = args.samples
+        for p in scene.pipelines:
+            p["samples"] = args.samples
     tiles_mode = args.mode == "tiles" and world > 1
     # the tiles mode gathers every frame before the next starts: one image is all it can use
     run = SceneRunner(scene, ordinal=local_rank, frames_in_flight=1 if tiles_mode else args.frames_in_flight)
@@ -218,8 +224,9 @@ def main():
             "higher_is_better": True, "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None,
             "dtype": "f32+i32", "data": "synthetic",
             "mtri_per_s": round(mtri, 2),
-            "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, 1 sample/pixel" % (
-                scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws)),
+            "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, %d sample%s/pixel" % (
+                scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws), scene.samples,
+                "" if scene.samples == 1 else "s"),
                 "sharding": ("tiles of one frame over %d GPUs + RCCL all_gather" % world) if tiles_mode
                 else ("one view per GPU, %d GPUs" % world), "frames_in_flight": run.frames_in_flight,
                 "seed": scene.seed},

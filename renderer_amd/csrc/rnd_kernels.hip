@@ -545,6 +545,41 @@ struct EdgeSetup {
     }
 };
 
+/* Multisample walk of pixels k0 .. k1-1 (row order) of a box whose first pixel is (x0, y0) and whose
+ * width is w, starting at (row, col).  The edge values are stepped per pixel at the pixel's corner;
+ * a sample's value is the corner's plus a constant per edge and sample (ownership bias folded in),
+ * so a pixel costs adds only. */
+template <int S>
+__device__ __forceinline__ void walk_samples(const EdgeSetup<int32_t, S>& es, const TileCtx& tc, int x0, int y0, int w,
+                                             int k0, int k1, int row, int col)
+{
+    const int32_t px = (x0 + col) * 256, py = (y0 + row) * 256;
+    int32_t e0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0);
+    int32_t e1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1);
+    int32_t e2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2);
+    int32_t o0[S], o1[S], o2[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        o0[s] = edge_mul(es.dx0, (int32_t)c_sample_y4[s]) - edge_mul(es.dy0, (int32_t)c_sample_x4[s]) - es.bias0;
+        o1[s] = edge_mul(es.dx1, (int32_t)c_sample_y4[s]) - edge_mul(es.dy1, (int32_t)c_sample_x4[s]) - es.bias1;
+        o2[s] = edge_mul(es.dx2, (int32_t)c_sample_y4[s]) - edge_mul(es.dy2, (int32_t)c_sample_x4[s]) - es.bias2;
+    }
+    const int32_t sx0 = -(es.dy0 << 8), sx1 = -(es.dy1 << 8), sx2 = -(es.dy2 << 8);
+    const int32_t nl0 = (es.dx0 << 8) - (w - 1) * sx0, nl1 = (es.dx1 << 8) - (w - 1) * sx1, nl2 = (es.dx2 << 8) - (w - 1) * sx2;
+    uint32_t pix = (uint32_t)((y0 + row - tc.py0) * TILE_W + (x0 + col - tc.px0));
+    for (int i = k0; i < k1; ++i) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int32_t a0 = e0 + o0[s], a1 = e1 + o1[s], a2 = e2 + o2[s];
+            if ((a0 | a1 | a2) >= 0) es.emit(tc, pix * S + s, a1 + es.bias1, a2 + es.bias2);
+        }
+        const bool last = ++col == w;
+        e0 += last ? nl0 : sx0; e1 += last ? nl1 : sx1; e2 += last ? nl2 : sx2;
+        pix += last ? (uint32_t)(TILE_W - w + 1) : 1u;
+        if (last) col = 0;
+    }
+}
+
 __device__ __forceinline__ bool tri_box_in_tile(const FrameParams& fp, const TileCtx& tc, const RasterTri& t,
                                                 int& x0, int& y0, int& x1, int& y1)
 {
@@ -594,11 +629,7 @@ __device__ __forceinline__ void raster_lane(const FrameParams& fp, const TileCtx
             if (last) col = 0;
         }
     } else {
-        int x = x0, y = y0;
-        for (int i = 0; i < count; ++i) {
-            es.pixel(tc, x, y);
-            if (++x > x1) { x = x0; ++y; }
-        }
+        walk_samples<S>(es, tc, x0, y0, w, 0, count, 0, 0);
     }
 }
 
@@ -646,7 +677,7 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
  * triangle from its lane and walks the chunk.  Every lane then has at most CHUNK_PIXELS steps per
  * round whatever the mix of box sizes, and nothing is left to the whole-wave path except triangles
  * too large for 32-bit edge products. */
-constexpr int DIRECT_PIXELS = 32; /* measured: 16-pixel chunks balance best, but a wave of boxes up to 32 pixels is quicker walked as it is */
+constexpr int DIRECT_PIXELS = 32; /* measured: 16-pixel chunks balance best, but a wave of boxes up to 32 pixels is quicker walked as it is; the same holds at four samples per pixel */
 constexpr int CHUNK_PIXELS = 16;
 
 template <int S>
@@ -707,11 +738,7 @@ __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileC
                 if (last) col = 0;
             }
         } else {
-            int x = ox0 + col, y = oy0 + row;
-            for (int i = k0; i < k1; ++i) {
-                es.pixel(tc, x, y);
-                if (++x >= ox0 + ow) { x = ox0; ++y; }
-            }
+            walk_samples<S>(es, tc, ox0, oy0, ow, k0, k1, row, col);
         }
     }
 }
