@@ -80,20 +80,21 @@ def cpu_baseline(scene, budget_s=12.0):
                 frames, scene.name, scene.width, scene.height, scene.triangle_count(), el)}
 
 
-def measured_traffic(kernel, config):
-    """HBM bytes per launch of `kernel` from the committed counter pass of this workload
-    (profiles/traffic.json, written by tools/summarize_profiles.py from rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE runs of this same command), or None when there is none."""
+def measured_counters(kernel, config):
+    """The committed counter pass of this workload for `kernel` (profiles/traffic.json, written by
+    tools/summarize_profiles.py from rocprofv3 --pmc runs of this same command): HBM bytes per
+    launch (FETCH_SIZE / WRITE_SIZE) and vector-ALU instructions per launch (SQ_INSTS_VALU).
+    (None, None) when there is no pass for this workload."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             table = json.load(f).get("config%d" % config, {})
     except (OSError, ValueError):
-        return None
+        return None, None
     for name, row in table.items():
         if name.split("<")[0] == kernel:
-            return int(row["read_bytes"] + row["write_bytes"])
-    return None
+            return int(row["read_bytes"] + row["write_bytes"]), row.get("valu_insts")
+    return None, None
 
 
 def main():
@@ -206,11 +207,16 @@ def main():
         if tiles_mode:
             share = share / world
         achieved = share / (stages[dom] * 1e-3) / 1e9
+        traffic, valu = measured_counters("k_" + dom, args.config) if args.samples == 1 else (None, None)
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": measured_traffic("k_" + dom, args.config),
+                    "traffic": traffic,
                     "algorithmic_bytes_per_launch": share,
                     "kernel_ms": round(stages[dom], 5)}
+        if valu:
+            # what the kernel is actually short of: a wave's vector instruction occupies its SIMD
+            # for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+            roofline["valu_busy"] = round(valu * 4.0 / (1024 * stages[dom] * 1e-3 * 2.4e9), 4)
 
     cpu = None
     if rank == 0 and not args.no_cpu:

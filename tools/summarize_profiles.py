@@ -60,7 +60,7 @@ def main(src, dst_prefix, config=None):
         if "FETCH_SIZE" in r and "WRITE_SIZE" in r:
             short = n.split("(")[0].replace("void ", "").replace("rnd::", "")
             traffic[short] = {"read_bytes": 2.0 * r["FETCH_SIZE"] * 1024.0, "write_bytes": r["WRITE_SIZE"] * 1024.0,
-                              "avg_us": r.get("avg_us")}
+                              "avg_us": r.get("avg_us"), "valu_insts": r.get("SQ_INSTS_VALU")}
     with open(dst_prefix + "_traffic.json", "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     print("wrote", dst_prefix + "_pmc.csv", dst_prefix + "_traffic.json")
