@@ -7,6 +7,10 @@
 //
 //   test_ktx_app_headless [--width W] [--height H] [--frames N] [--out frame.ppm]
 //                         [--shader ktx|push_constants] [--dump-ubo]
+//
+// Built with -DSAMPLE_PUSH_CONSTANTS the same source is the reference's test_push_constants sample
+// (src/samples/test_push_constants_app/test_push_constants_app.cpp:562-681): the same ring of ten
+// draws with push_constants.{vert,frag}, whose descriptor set holds the uniform block and no texture.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +23,12 @@
 using namespace rnd_host;
 
 namespace {
+
+#ifdef SAMPLE_PUSH_CONSTANTS
+constexpr int DEFAULT_SHADER = RND_SHADER_PUSH_CONSTANTS;
+#else
+constexpr int DEFAULT_SHADER = RND_SHADER_TEST_KTX;
+#endif
 
 struct push_constant_data { // test_ktx_app.hpp:16-19
     glm_lite::vec4 color;
@@ -97,7 +107,7 @@ public:
                 if (m_graphics_pipelines[g].handle() != last_pipeline) {
                     RND_CHECK(rnd_cmd_bind_pipeline(cmd, m_graphics_pipelines[g]));
                     RND_CHECK(rnd_cmd_bind_uniform(cmd, 0, 0, m_ubo, 0, sizeof(global_ubo)));
-                    RND_CHECK(rnd_cmd_bind_texture(cmd, 0, 1, m_model.textures[0]));
+                    if (m_shader == RND_SHADER_TEST_KTX) RND_CHECK(rnd_cmd_bind_texture(cmd, 0, 1, m_model.textures[0]));
                     last_pipeline = m_graphics_pipelines[g];
                 }
                 const obj_sub_geometry& sg = m_model.sub_geometries[g];
@@ -149,7 +159,7 @@ uint64_t fnv1a(const void* data, size_t n, uint64_t h = 1469598103934665603ull)
 ERROR_TYPE run(int argc, const char** argv)
 {
     uint32_t w = 1280, h = 720;
-    int frames = 3, shader = RND_SHADER_TEST_KTX;
+    int frames = 3, shader = DEFAULT_SHADER;
     bool dump_ubo = false;
     std::string out;
     for (int i = 1; i < argc; ++i) {

@@ -12,6 +12,7 @@ from renderer_amd import hostmath as hm, scenes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAMPLE = os.path.join(ROOT, "samples", "test_ktx_app_headless")
 SAMPLE_NOEXC = os.path.join(ROOT, "samples", "test_ktx_app_headless_noexcept")
+SAMPLE_PUSH = os.path.join(ROOT, "samples", "test_push_constants_app_headless")
 
 
 def dump_ubo(w, h):
@@ -70,14 +71,15 @@ def cpp_checker(size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exe", [SAMPLE, SAMPLE_NOEXC])
+@pytest.mark.parametrize("exe", [SAMPLE, SAMPLE_NOEXC, SAMPLE_PUSH])
 def test_sample_frame_matches_oracle(oracle, exe):
     w, h = 320, 180
     out = subprocess.run([exe, "--frames", "1", "--width", str(w), "--height", str(h)], check=True,
                          capture_output=True, text=True).stdout
     fields = dict(f.split("=") for f in out.split())
     ubo, ring = dump_ubo(w, h)
-    sc = scenes.config0(w, h, tex_size=16)
+    # the push-constants sample: the same ring, lit by the push colour instead of a texture
+    sc = scenes.config0(w, h, tex_size=16, shader=scenes.SHADER_PUSH_CONSTANTS if exe == SAMPLE_PUSH else scenes.SHADER_TEST_KTX)
     sc.textures[0]["texels"] = cpp_checker(1024)
     sc.ubos[0] = ubo
     for j, d in enumerate(sc.draws):
