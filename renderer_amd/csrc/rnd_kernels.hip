@@ -1251,9 +1251,6 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     __shared__ unsigned long long keys[TILE_PIXELS * S];
     __shared__ ShadeTables tb;
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
-    stage_tables(tb, fp.tables);
-    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
-
     uint32_t tile, utx, uty;
     if (fp.shard_count == 1) {
         rows_of_eight(blockIdx.x, fp.tiles_x, magic, utx, uty);
@@ -1270,20 +1267,27 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     tc.rx1 = min(tc.px0 + TILE_W - 1, fp.clamp_x1); tc.ry1 = min(tc.py0 + TILE_H - 1, fp.clamp_y1);
     tc.keys = keys;
 
+    /* the length of the tile's list is asked for first: its round trip runs under the staging of
+     * the tables and the clearing of the tile's words */
+    const bool visible = tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1;
+    const uint32_t listed = visible ? fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE] : 0u;
+    const uint32_t listed_large = visible ? fp.counters[CTR_LARGE] : 0u;
+    stage_tables(tb, fp.tables);
+    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
     for (uint32_t i = threadIdx.x; i < TILE_PIXELS * S; i += TILE_THREADS) keys[i] = clear_key;
     __syncthreads();
 
-    if (tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1 && !RND_PROBE(fp, 2u)) {
+    if (visible && !RND_PROBE(fp, 2u)) {
         /* this tile's list: 16-byte entries, one per lane per batch */
-        uint32_t count = min(fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE], fp.tile_capacity);
+        uint32_t count = min(listed, fp.tile_capacity);
         if (RND_PROBE(fp, 16u)) count = min(count, 256u);
         if (RND_PROBE(fp, 64u)) count = min(count, 512u);
         const TileEntry* list = fp.tile_lists + (size_t)tile * fp.tile_stride;
         raster_stream<S>(fp, tc, count, [&](uint32_t i, TileEntry& e) -> bool { e = list[i]; return true; });
         /* the pass-wide list: primitives spanning many tiles, and spill of full tile lists */
-        const uint32_t n_large = min(fp.counters[CTR_LARGE], fp.large_capacity);
+        const uint32_t n_large = min(listed_large, fp.large_capacity);
         raster_stream<S>(fp, tc, n_large, [&](uint32_t i, TileEntry& e) -> bool {
             const LargeEntry le = fp.large_list[i];
             const int bx0 = le.box & 255u, by0 = (le.box >> 8) & 255u, bx1 = (le.box >> 16) & 255u, by1 = le.box >> 24;
