@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--mode", choices=["views", "tiles"], default="views")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="command buffers / targets the frames rotate through (the reference's swapchain image count)")
+    ap.add_argument("--one-shard-of", type=int, default=1, metavar="N",
+                    help="single-GPU rehearsal of the tiles mode: render only the tiles rank 0 of N would own, no exchange")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=20)
     args = ap.parse_args()
@@ -117,11 +119,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    # BENCH_BACKEND=gloo rehearses the multi-rank paths on a box with fewer GPUs than ranks: the ranks
+    # share the GPUs that are there and the exchange goes through host memory (numbers mean nothing)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
@@ -135,6 +145,9 @@ def main():
     run = SceneRunner(scene, ordinal=local_rank, frames_in_flight=1 if tiles_mode else args.frames_in_flight)
     if tiles_mode:
         run.cmd.set_tile_shard(rank, world)
+    elif args.one_shard_of > 1:
+        for c in run.cmds:
+            c.set_tile_shard(0, args.one_shard_of)
 
     def sync():
         run.dev.wait_idle()
@@ -147,25 +160,31 @@ def main():
     n_ubos = args.warmup + max(args.steps, args.profile_steps)
     ubos = [orbit_ubo(scene, i, 0 if tiles_mode else rank) for i in range(n_ubos)]
 
-    def step(i):
+    def render_step(i):
         run.set_ubo(0, ubos[i])
         run.submit()
 
-    gather_ms = None
+    step = render_step
+
+    gather_s = [0.0]  # tiles mode: time spent after the rank's own tiles are rendered (copy-out, all_gather, put-back)
     if tiles_mode:
         from renderer_amd import sharding
         mine = torch.empty((scene.height, scene.width, 4), dtype=torch.uint8, device="cuda")
 
         def step(i):  # noqa: F811 - one frame = render own tiles, then gather the colour image
-            run.set_ubo(0, ubos[i])
-            run.submit()
+            render_step(i)
             run.target.copy_color(mine.data_ptr())
             run.dev.wait_idle()
-            return sharding.gather_frame(mine, dist, world)
+            t_g = time.perf_counter()
+            frame = sharding.gather_frame(mine if backend == "nccl" else mine.cpu(), dist, world, rank)
+            torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - t_g
+            return frame
 
     for i in range(args.warmup):
         step(i)
     sync()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -180,6 +199,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gather_ms = gather_s[0] / args.steps * 1e3 if tiles_mode else None
+    tiles_check = None
+    if tiles_mode:
+        # the gathered frame against the same frame rendered whole on this rank
+        frame = step(0).cpu().numpy()
+        whole = SceneRunner(scene, ordinal=local_rank)
+        whole.set_ubo(0, ubos[0])
+        color, _ = whole.render()
+        whole.destroy()
+        tiles_check = "exact" if np.array_equal(frame, color) else "%d bytes differ" % int((frame != color).sum())
+        if tiles_check != "exact":
+            raise SystemExit("tile-sharded frame differs from the unsharded frame: " + tiles_check)
     frames_total = args.steps * (1 if tiles_mode else world)
     pixels = scene.width * scene.height
     mpix = pixels * frames_total / elapsed / 1e6
@@ -192,7 +223,7 @@ def main():
         run.dev.set_profiling(True)
         acc = {}
         for i in range(args.profile_steps):
-            step(i)
+            render_step(i)  # this rank alone: no exchange here
             run.dev.wait_idle()
             for k, v in run.dev.stage_times().items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -207,7 +238,7 @@ def main():
         if tiles_mode:
             share = share / world
         achieved = share / (stages[dom] * 1e-3) / 1e9
-        traffic, valu = measured_counters("k_" + dom, args.config) if args.samples == 1 else (None, None)
+        traffic, valu = measured_counters("k_" + dom, args.config) if args.samples == 1 and not tiles_mode and args.one_shard_of == 1 else (None, None)  # counter passes are whole frames at one sample
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic,
@@ -234,11 +265,15 @@ def main():
                 scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws), scene.samples,
                 "" if scene.samples == 1 else "s"),
                 "sharding": ("tiles of one frame over %d GPUs + RCCL all_gather" % world) if tiles_mode
+                else ("rehearsal: the tiles of rank 0 of %d only" % args.one_shard_of) if args.one_shard_of > 1
                 else ("one view per GPU, %d GPUs" % world), "frames_in_flight": run.frames_in_flight,
                 "seed": scene.seed},
             "frame_algorithmic_bytes": scene.algorithmic_bytes(),
             "frame_hbm_frac": round(scene.algorithmic_bytes() * frames_total / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "stage_ms": {k: round(v, 5) for k, v in stages.items()},
+            "tiles_check": tiles_check,
+            "gather_ms": None if gather_ms is None else round(gather_ms, 5),
+            "render_ms": None if gather_ms is None else round(elapsed / args.steps * 1e3 - gather_ms, 5),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

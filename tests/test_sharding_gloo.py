@@ -48,6 +48,26 @@ def test_tile_gather_over_gloo(tmp_path, oracle, world):
         assert np.load(str(tmp_path / ("t_%d.npy" % r)))[0] == float(world)
 
 
+@pytest.mark.parametrize("wh", [(200, 150), (64, 96), (33, 31)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_pack_and_unpack_tiles(wh, world):
+    """Slabs of owned tiles, stacked as the all_gather stacks them, give the image back: sizes that
+    are and are not multiples of the tile, ranks with one tile fewer than others, more ranks than tiles."""
+    import torch
+    w, h = wh
+    rng = np.random.RandomState(5)
+    full = torch.from_numpy(rng.randint(0, 256, (h, w, 4)).astype(np.uint8))
+    own = torch.from_numpy(sharding.tile_owner_map(w, h, world))
+    slabs = []
+    for r in range(world):
+        mine = torch.where((own == r)[..., None], full, torch.zeros_like(full))  # tiles of others: not rendered
+        slabs.append(sharding.pack_owned_tiles(mine, r, world))
+    assert len({tuple(s.shape) for s in slabs}) == 1
+    tiles = ((w + 31) // 32) * ((h + 31) // 32)
+    assert slabs[0].shape[0] == (tiles + world - 1) // world
+    assert torch.equal(sharding.unpack_tiles(torch.stack(slabs), w, h), full)
+
+
 def test_owner_map_matches_kernel_rule():
     """tile t = ty * tiles_x + tx belongs to rank t % world; every pixel has exactly one owner."""
     own = sharding.tile_owner_map(100, 70, 3)
