@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the draw path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4] [--mode views|tiles]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4] [--mode views|tiles|bands]
 
 One step = one frame: write the 320-byte uniform block (a new camera, as the reference's
 draw_frame does every frame, base_obj_viewer_app.cpp:90-141) and submit the pre-recorded
@@ -12,7 +12,9 @@ N = 1 renders BASELINE.json's configs[1]: 1920x1080, one draw of 1 002 528 trian
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own
 view of that scene (independent views sharded over GPUs, no collective on the data path,
 weak scaling); --mode tiles instead shards the 32x32 tiles of ONE frame over the ranks
-and gathers the finished colour image with an RCCL all_gather (strong scaling).
+and gathers the finished colour image with an RCCL all_gather (strong scaling); --mode bands
+gives every rank a band of whole rows of tiles as its render area, so that the library also skips
+the draws outside the band, and gathers the bands the same way.
 
 Prints ONE JSON line on rank 0.
 """
@@ -105,11 +107,13 @@ def main():
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--samples", type=int, choices=[1, 4], default=1,
                     help="samples per pixel (4: what test_app renders with, dummy_obj_viewer_app.cpp:319; resolved in linear light)")
-    ap.add_argument("--mode", choices=["views", "tiles"], default="views")
+    ap.add_argument("--mode", choices=["views", "tiles", "bands"], default="views")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="command buffers / targets the frames rotate through (the reference's swapchain image count)")
     ap.add_argument("--one-shard-of", type=int, default=1, metavar="N",
-                    help="single-GPU rehearsal of the tiles mode: render only the tiles rank 0 of N would own, no exchange")
+                    help="single-GPU rehearsal of the tiles mode (or, with --mode bands, the bands mode): render only what "
+                         "rank --shard-rank of N would own, no exchange")
+    ap.add_argument("--shard-rank", type=int, default=0, help="which rank's share --one-shard-of renders")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=20)
     args = ap.parse_args()
@@ -140,14 +144,19 @@ def main():
         scene.samples = args.samples
         for p in scene.pipelines:
             p["samples"] = args.samples
-    tiles_mode = args.mode == "tiles" and world > 1
-    # the tiles mode gathers every frame before the next starts: one image is all it can use
+    bands = args.mode == "bands"
+    tiles_mode = args.mode in ("tiles", "bands") and world > 1
+    whole_scene = scene
+    if bands and (world > 1 or args.one_shard_of > 1):
+        from renderer_amd import sharding
+        scene = sharding.band_scene(scene, *((rank, world) if world > 1 else (args.shard_rank, args.one_shard_of)))
+    # the sharded modes gather every frame before the next starts: one image is all they can use
     run = SceneRunner(scene, ordinal=local_rank, frames_in_flight=1 if tiles_mode else args.frames_in_flight)
-    if tiles_mode:
+    if tiles_mode and not bands:
         run.cmd.set_tile_shard(rank, world)
-    elif args.one_shard_of > 1:
+    elif args.one_shard_of > 1 and not bands:
         for c in run.cmds:
-            c.set_tile_shard(0, args.one_shard_of)
+            c.set_tile_shard(args.shard_rank, args.one_shard_of)
 
     def sync():
         run.dev.wait_idle()
@@ -169,14 +178,22 @@ def main():
     gather_s = [0.0]  # tiles mode: time spent after the rank's own tiles are rendered (copy-out, all_gather, put-back)
     if tiles_mode:
         from renderer_amd import sharding
-        mine = torch.empty((scene.height, scene.width, 4), dtype=torch.uint8, device="cuda")
+        if bands:
+            y0, y1 = sharding.band_rows(scene.height, rank, world)
+            mine = torch.empty((y1 - y0, scene.width, 4), dtype=torch.uint8, device="cuda")
+        else:
+            mine = torch.empty((scene.height, scene.width, 4), dtype=torch.uint8, device="cuda")
 
         def step(i):  # noqa: F811 - one frame = render own tiles, then gather the colour image
             render_step(i)
-            run.target.copy_color(mine.data_ptr())
+            if bands:
+                run.target.copy_color_rows(y0, y1 - y0, mine.data_ptr())
+            else:
+                run.target.copy_color(mine.data_ptr())
             run.dev.wait_idle()
             t_g = time.perf_counter()
-            frame = sharding.gather_frame(mine if backend == "nccl" else mine.cpu(), dist, world, rank)
+            part = mine if backend == "nccl" else mine.cpu()
+            frame = sharding.gather_bands(part, dist, world, scene.height) if bands else sharding.gather_frame(part, dist, world, rank)
             torch.cuda.synchronize()
             gather_s[0] += time.perf_counter() - t_g
             return frame
@@ -204,7 +221,7 @@ def main():
     if tiles_mode:
         # the gathered frame against the same frame rendered whole on this rank
         frame = step(0).cpu().numpy()
-        whole = SceneRunner(scene, ordinal=local_rank)
+        whole = SceneRunner(whole_scene, ordinal=local_rank)
         whole.set_ubo(0, ubos[0])
         color, _ = whole.render()
         whole.destroy()
@@ -264,8 +281,8 @@ def main():
             "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, %d sample%s/pixel" % (
                 scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws), scene.samples,
                 "" if scene.samples == 1 else "s"),
-                "sharding": ("tiles of one frame over %d GPUs + RCCL all_gather" % world) if tiles_mode
-                else ("rehearsal: the tiles of rank 0 of %d only" % args.one_shard_of) if args.one_shard_of > 1
+                "sharding": ("%s of one frame over %d GPUs + RCCL all_gather" % (args.mode, world)) if tiles_mode
+                else ("rehearsal: the %s of rank %d of %d only" % (args.mode if bands else "tiles", args.shard_rank, args.one_shard_of)) if args.one_shard_of > 1
                 else ("one view per GPU, %d GPUs" % world), "frames_in_flight": run.frames_in_flight,
                 "seed": scene.seed},
             "frame_algorithmic_bytes": scene.algorithmic_bytes(),

@@ -154,6 +154,9 @@ void* rnd_target_color_device_ptr(rnd_target target); /* resolved colour image i
  * (width*height*4 bytes) on the device's stream, e.g. into the send buffer of the
  * multi-GPU frame gather.  Does not wait. */
 int rnd_target_copy_color(rnd_target target, void* device_dst);
+/* the same for rows [first_row, first_row + row_count) only (row_count*width*4 bytes): what a device
+ * that renders one band of the frame (its render area) contributes to the gather */
+int rnd_target_copy_color_rows(rnd_target target, uint32_t first_row, uint32_t row_count, void* device_dst);
 int rnd_target_destroy(rnd_target target);
 
 /* vkCreateGraphicsPipelines (test_ktx_app.cpp:607-620) */
@@ -187,6 +190,15 @@ int rnd_cmd_destroy(rnd_cmd cmd);
  * tiles t with t % shard_count == shard_index; other pixels of the target are left
  * untouched.  (0,1) renders everything.  Takes effect at the next submit. */
 int rnd_cmd_set_tile_shard(rnd_cmd cmd, uint32_t shard_index, uint32_t shard_count);
+/* The other way to shard a frame needs no call of its own: give each device a band of the frame as
+ * its render area and scissor (rnd_cmd_begin_pass / rnd_cmd_set_scissor, the reference's renderArea
+ * and vkCmdSetScissor).  Only the tiles the render area touches are launched, and a draw whose box
+ * of vertices misses the scissored rectangle is skipped whole when the work executes, so a band
+ * costs its own share of the geometry work as well as of the pixels.  Pixels inside the band are
+ * the same as in the unsharded frame. */
+/* no reference analogue (a statistic for tests and tuning): how many draws of the command buffer's
+ * last executed frame were kept, i.e. had vertices and were not skipped whole.  Waits for the device. */
+int rnd_cmd_visible_draws(rnd_cmd cmd, uint32_t* out_count);
 
 /* vkQueueSubmit (vk_app.cpp:463-467).  The command buffer can be resubmitted; uniform
  * buffers are read when the work executes, so a buffer_write between two submits of the

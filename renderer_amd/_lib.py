@@ -18,12 +18,12 @@ SYMBOLS = [
     "rnd_buffer_create", "rnd_buffer_write", "rnd_buffer_write_device", "rnd_buffer_read", "rnd_buffer_destroy",
     "rnd_texture_create_2d", "rnd_texture_create_levels", "rnd_texture_level_count", "rnd_texture_read_level",
     "rnd_texture_destroy",
-    "rnd_target_create", "rnd_target_read", "rnd_target_color_device_ptr", "rnd_target_copy_color", "rnd_target_destroy",
+    "rnd_target_create", "rnd_target_read", "rnd_target_color_device_ptr", "rnd_target_copy_color", "rnd_target_copy_color_rows", "rnd_target_destroy",
     "rnd_pipeline_create", "rnd_pipeline_destroy",
     "rnd_cmd_create", "rnd_cmd_begin", "rnd_cmd_begin_pass", "rnd_cmd_set_viewport", "rnd_cmd_set_scissor",
     "rnd_cmd_bind_pipeline", "rnd_cmd_bind_vertex_buffer", "rnd_cmd_bind_index_buffer", "rnd_cmd_bind_uniform",
     "rnd_cmd_bind_texture", "rnd_cmd_push_constants", "rnd_cmd_draw_indexed", "rnd_cmd_end_pass", "rnd_cmd_end",
-    "rnd_cmd_destroy", "rnd_cmd_set_tile_shard",
+    "rnd_cmd_destroy", "rnd_cmd_set_tile_shard", "rnd_cmd_visible_draws",
     "rnd_submit",
     "rnd_fence_create", "rnd_fence_wait", "rnd_fence_destroy",
 ]
@@ -84,6 +84,7 @@ def load():
         "rnd_target_read": (C.c_int, [vp, vp, vp]),
         "rnd_target_color_device_ptr": (vp, [vp]),
         "rnd_target_copy_color": (C.c_int, [vp, vp]),
+        "rnd_target_copy_color_rows": (C.c_int, [vp, u32, u32, vp]),
         "rnd_target_destroy": (C.c_int, [vp]),
         "rnd_pipeline_create": (C.c_int, [vp, C.POINTER(PipelineInfo), C.POINTER(vp)]),
         "rnd_pipeline_destroy": (C.c_int, [vp]),
@@ -103,6 +104,7 @@ def load():
         "rnd_cmd_end": (C.c_int, [vp]),
         "rnd_cmd_destroy": (C.c_int, [vp]),
         "rnd_cmd_set_tile_shard": (C.c_int, [vp, u32, u32]),
+        "rnd_cmd_visible_draws": (C.c_int, [vp, C.POINTER(u32)]),
         "rnd_submit": (C.c_int, [vp, vp, vp]),
         "rnd_fence_create": (C.c_int, [vp, C.POINTER(vp)]),
         "rnd_fence_wait": (C.c_int, [vp]),

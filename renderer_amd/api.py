@@ -181,6 +181,10 @@ class Target(_Handle):
         """Queue a device-to-device copy of the colour image; does not wait."""
         _check(_lib.load().rnd_target_copy_color(self.h, C.c_void_p(device_ptr)))
 
+    def copy_color_rows(self, first_row, row_count, device_ptr):
+        """The same for rows [first_row, first_row + row_count) only."""
+        _check(_lib.load().rnd_target_copy_color_rows(self.h, first_row, row_count, C.c_void_p(device_ptr)))
+
 
 class Pipeline(_Handle):
     _destroy_name = "rnd_pipeline_destroy"
@@ -273,3 +277,9 @@ class CommandBuffer(_Handle):
 
     def set_tile_shard(self, index, count):
         _check(_lib.load().rnd_cmd_set_tile_shard(self.h, index, count))
+
+    def visible_draws(self):
+        """Draws of the last executed frame that were not skipped whole (waits for the device)."""
+        n = C.c_uint32(0)
+        _check(_lib.load().rnd_cmd_visible_draws(self.h, C.byref(n)))
+        return n.value

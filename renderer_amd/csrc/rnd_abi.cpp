@@ -13,7 +13,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <map>
+#include <tuple>
 #include <string>
 #include <utility>
 #include <algorithm>
@@ -680,6 +682,20 @@ int rnd_target_copy_color(rnd_target target, void* device_dst)
     return RND_SUCCESS;
 }
 
+int rnd_target_copy_color_rows(rnd_target target, uint32_t first_row, uint32_t row_count, void* device_dst)
+{
+    if (!target || !device_dst) return fail(RND_ERROR_INVALID_ARGUMENT, "target_copy_color_rows: bad arguments");
+    if (first_row > target->height || row_count > target->height - first_row) return fail(RND_ERROR_INVALID_ARGUMENT, "target_copy_color_rows: rows outside the image");
+    if (int r = set_device(target->dev)) return r;
+    if (!row_count) return RND_SUCCESS;
+    hipStream_t s = target->last_valid ? target->last_stream : target->dev->stream;
+    const size_t pitch = (size_t)target->width * 4;
+    HIP_TRY(hipMemcpyAsync(device_dst, target->color + (size_t)first_row * pitch, (size_t)row_count * pitch, hipMemcpyDeviceToDevice, s));
+    target->last_stream = s; target->last_valid = true;
+    if (s == target->dev->stream) target->dev->stream_dirty = true;
+    return RND_SUCCESS;
+}
+
 int rnd_target_destroy(rnd_target target)
 {
     if (!target) return RND_SUCCESS;
@@ -907,6 +923,20 @@ int rnd_cmd_set_tile_shard(rnd_cmd cmd, uint32_t shard_index, uint32_t shard_cou
     return RND_SUCCESS;
 }
 
+int rnd_cmd_visible_draws(rnd_cmd cmd, uint32_t* out_count)
+{
+    if (!cmd || !out_count) return fail(RND_ERROR_INVALID_ARGUMENT, "cmd_visible_draws: bad arguments");
+    if (cmd->state != CMD_EXECUTABLE) return fail(RND_ERROR_RECORDING, "command buffer is not in the executable state");
+    if (int r = set_device(cmd->dev)) return r;
+    HIP_TRY(sync_all(cmd->dev));
+    std::vector<DrawDerived> dd(cmd->d_derived.count);
+    if (!dd.empty()) HIP_TRY(hipMemcpy(dd.data(), cmd->d_derived.ptr, dd.size() * sizeof(DrawDerived), hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    for (const DrawDerived& d : dd) n += d.visible ? 1u : 0u;
+    *out_count = n;
+    return RND_SUCCESS;
+}
+
 /* Turns the recorded draws into device tables.  Runs once per recording, like the
  * reference's record_command_buffers (recorded once, submitted every frame). */
 int rnd_cmd_end(rnd_cmd cmd)
@@ -990,12 +1020,68 @@ int rnd_cmd_end(rnd_cmd cmd)
         d_jobs.release(); d_max.release();
     }
 
-    std::vector<Chunk> vchunks, tchunks;
-    uint64_t svtx_total = 0, prim_total = 0;
     for (size_t i = 0; i < n; ++i) {
         DrawStatic& d = ds[i];
         uint64_t want = (uint64_t)job_max[job_of[i]] + 1;
         d.vert_count = d.tri_count ? (uint32_t)std::min<uint64_t>(want, d.vb_capacity) : 0;
+    }
+
+    /* The box of every draw's vertices, for culling whole draws when the work executes.  A pass of one
+     * draw gets none (that draw is the pass).  Draws over the same vertices share one job. */
+    if (n >= 2) {
+        std::vector<BoundsJob> bjobs;
+        std::vector<uint32_t> bjob_of(n, 0xFFFFFFFFu);
+        std::map<std::tuple<const uint8_t*, uint32_t, int32_t, uint32_t>, uint32_t> bjob_map;
+        for (size_t i = 0; i < n; ++i) {
+            const DrawStatic& d = ds[i];
+            if (!d.vert_count) continue;
+            auto key = std::make_tuple(d.vb, d.stride, d.off_pos, d.vert_count);
+            auto it = bjob_map.find(key);
+            if (it == bjob_map.end()) {
+                it = bjob_map.emplace(key, (uint32_t)bjobs.size()).first;
+                bjobs.push_back(BoundsJob{d.vb, d.stride, (uint32_t)d.off_pos, d.vert_count, 0});
+            }
+            bjob_of[i] = it->second;
+        }
+        if (!bjobs.empty()) {
+            std::vector<uint32_t> boxes(bjobs.size() * 6);
+            for (size_t j = 0; j < bjobs.size(); ++j)
+                for (int k = 0; k < 6; ++k) boxes[j * 6 + k] = k < 3 ? 0xFFFFFFFFu : 0u;
+            DeviceArray<BoundsJob> d_bjobs;
+            DeviceArray<uint32_t> d_boxes;
+            HIP_TRY(d_bjobs.upload(bjobs));
+            HIP_TRY(d_boxes.upload(boxes));
+            for (size_t b = 0; b < bjobs.size(); b += 32768) {
+                uint32_t cnt = (uint32_t)std::min<size_t>(32768, bjobs.size() - b);
+                launch_bounds(d_bjobs.ptr + b, d_boxes.ptr + b * 6, cnt, dev->stream);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(dev->stream));
+            HIP_TRY(hipMemcpy(boxes.data(), d_boxes.ptr, boxes.size() * 4, hipMemcpyDeviceToHost));
+            d_bjobs.release(); d_boxes.release();
+            auto from_ordered = [](uint32_t o) -> float {
+                uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+                float f; memcpy(&f, &b, 4); return f;
+            };
+            for (size_t i = 0; i < n; ++i) {
+                if (bjob_of[i] == 0xFFFFFFFFu) continue;
+                const uint32_t* bx = &boxes[(size_t)bjob_of[i] * 6];
+                bool ok = true;
+                for (int k = 0; k < 3; ++k) {
+                    if (bx[k] == 0xFFFFFFFFu && bx[3 + k] == 0u) { ok = false; break; } /* no vertex without a NaN */
+                    float lo = from_ordered(bx[k]), hi = from_ordered(bx[3 + k]);
+                    if (!std::isfinite(lo) || !std::isfinite(hi)) { ok = false; break; }
+                    ds[i].bounds_min[k] = lo; ds[i].bounds_max[k] = hi;
+                }
+                ds[i].has_bounds = ok ? 1u : 0u;
+            }
+        }
+    }
+
+    std::vector<Chunk> vchunks, tchunks;
+    uint64_t svtx_total = 0, prim_total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        DrawStatic& d = ds[i];
         if (svtx_total + d.vert_count > 0xFFFFFFFFull) return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "pass references more than 2^32 vertices");
         d.svtx_base = (uint32_t)svtx_total;
         svtx_total += d.vert_count;
@@ -1032,6 +1118,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     cmd->release_compiled();
     HIP_TRY(cmd->d_draws.upload(ds));
     HIP_TRY(cmd->d_derived.resize(n));
+    if (n) HIP_TRY(hipMemset(cmd->d_derived.ptr, 0, n * sizeof(DrawDerived))); /* a draw without vertices is never marked visible */
     HIP_TRY(cmd->d_vchunks.upload(vchunks));
     HIP_TRY(cmd->d_tchunks.upload(tchunks));
     HIP_TRY(cmd->d_textures.upload(td));
@@ -1074,6 +1161,16 @@ int rnd_cmd_end(rnd_cmd cmd)
     fp.shard_index = 0; fp.shard_count = 1;
     fp.area_x0 = cmd->area[0]; fp.area_y0 = cmd->area[1];
     fp.area_x1 = cmd->area[0] + cmd->area[2] - 1; fp.area_y1 = cmd->area[1] + cmd->area[3] - 1;
+    {
+        /* tiles the render area touches */
+        const int64_t ax0 = std::max<int64_t>(fp.area_x0, 0), ay0 = std::max<int64_t>(fp.area_y0, 0);
+        const int64_t ax1 = std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1), ay1 = std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1);
+        if (ax0 <= ax1 && ay0 <= ay1) {
+            fp.grid_x0 = (uint32_t)(ax0 / TILE_W); fp.grid_y0 = (uint32_t)(ay0 / TILE_H);
+            fp.grid_w = (uint32_t)(ax1 / TILE_W) - fp.grid_x0 + 1; fp.grid_h = (uint32_t)(ay1 / TILE_H) - fp.grid_y0 + 1;
+        }
+    }
+    fp.cull_lo_x = fp.cull_lo_y = -INFINITY; fp.cull_hi_x = fp.cull_hi_y = INFINITY;
     if (cmd->has_viewport && cmd->has_scissor) {
         const float* vp = cmd->viewport;
         fp.half_w = vp[2] * 0.5f; fp.half_h = vp[3] * 0.5f;
@@ -1087,9 +1184,21 @@ int rnd_cmd_end(rnd_cmd cmd)
         int64_t sx1 = (int64_t)cmd->scissor[0] + cmd->scissor[2] - 1, sy1 = (int64_t)cmd->scissor[1] + cmd->scissor[3] - 1;
         fp.clamp_x1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vx1, sx1), std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1));
         fp.clamp_y1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vy1, sy1), std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1));
+        /* the rectangle grown by a pixel, in normalised device coordinates (window = ndc * half + origin) */
+        if (fp.half_w > 0.0f && fp.clamp_x0 <= fp.clamp_x1) {
+            fp.cull_lo_x = ((float)fp.clamp_x0 - 1.0f - fp.ox) / fp.half_w;
+            fp.cull_hi_x = ((float)fp.clamp_x1 + 2.0f - fp.ox) / fp.half_w;
+        }
+        if (fp.half_h > 0.0f && fp.clamp_y0 <= fp.clamp_y1) {
+            fp.cull_lo_y = ((float)fp.clamp_y0 - 1.0f - fp.oy) / fp.half_h;
+            fp.cull_hi_y = ((float)fp.clamp_y1 + 2.0f - fp.oy) / fp.half_h;
+        }
     } else {
         fp.clamp_x0 = 0; fp.clamp_y0 = 0; fp.clamp_x1 = -1; fp.clamp_y1 = -1;
     }
+    /* an empty rectangle takes no fragment: the geometry kernels are not launched at all (the tile kernel
+     * still clears the render area) */
+    if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
     fp.direct_index = n == 1 ? 1u : 0u;
     fp.pass_shader = n ? ds[0].shader : -1;
     fp.pass_texture = n ? ds[0].texture : -1;

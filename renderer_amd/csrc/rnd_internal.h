@@ -118,14 +118,26 @@ struct DrawStatic {
     int32_t texture;
     uint32_t cull_mode, front_face;
     uint32_t prim_base;  /* running primitive number of triangle 0 (for diagnostics) */
-    uint32_t pad0;
+    uint32_t has_bounds; /* bounds_min / bounds_max hold the box of the draw's vertices (all finite) */
     float push[20];      /* vec4 colour, mat4 transform */
+    float bounds_min[3], bounds_max[3]; /* object space, over vertices [0, vert_count) */
+    uint32_t pad1[2];
 };
 
 /* Per-draw matrix derived from the uniform buffer each time the work executes: object space to
  * clip space.  The vertex kernel builds it per wave and stores it here for the clipper. */
 struct DrawDerived {
     float clip_m[16];
+    uint32_t visible; /* 0: the draw's box misses the frustum or the rectangle this device renders; setup skips it */
+    uint32_t pad[3];
+};
+
+/* Record-time job: the box of `count` positions read at vb + i * stride + off_pos.  The result is six
+ * words per job, minimum x y z then maximum x y z, as floats mapped to unsigned integers of the same order
+ * (float_to_ordered); the caller initialises them to 0xFFFFFFFF x3, 0 x3. */
+struct BoundsJob {
+    const uint8_t* vb;
+    uint32_t stride, off_pos, count, pad;
 };
 
 /* A small host write to a uniform buffer that has not reached device memory.  It rides in the
@@ -191,6 +203,11 @@ struct FrameParams {
     uint32_t color_srgb, color_bgra;
     uint32_t tiles_x, tiles_y;
     uint32_t shard_index, shard_count;
+    uint32_t grid_x0, grid_y0, grid_w, grid_h; /* the tiles the render area touches: only these are launched */
+    /* Draw culling: the clamp rectangle grown by one pixel, in normalised device coordinates.  A draw whose
+     * box of vertices lies wholly beyond one of these four planes, the near plane or the far plane has no
+     * fragment inside the rectangle (a device that renders one band of a frame skips the other bands' draws) */
+    float cull_lo_x, cull_hi_x, cull_lo_y, cull_hi_y;
     int32_t clamp_x0, clamp_y0, clamp_x1, clamp_y1; /* inclusive pixel rectangle fragments may land in */
     int32_t area_x0, area_y0, area_x1, area_y1;     /* inclusive render area (cleared and stored) */
     float half_w, half_h, ox, oy, pz, zmin;
@@ -210,6 +227,7 @@ struct FrameParams {
 
 /* launch wrappers (rnd_kernels.hip) */
 void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n_jobs, hipStream_t s);
+void launch_bounds(const BoundsJob* jobs, uint32_t* out_min_max, uint32_t n_jobs, hipStream_t s);
 void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s);
 void launch_setup(const FrameParams& fp, hipStream_t s);
 void launch_tile(const FrameParams& fp, hipStream_t s);

@@ -135,6 +135,46 @@ __global__ __launch_bounds__(256) void k_index_range(const IndexRangeJob* jobs, 
     if (any) atomicMax(&out_max[blockIdx.y], m);
 }
 
+/* ------------------------------------------------------------------ record-time: box of a draw's vertices */
+
+/* floats to unsigned integers of the same order (NaN sorts above +inf or below -inf and is skipped by the caller) */
+__device__ __forceinline__ uint32_t float_to_ordered(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+/* A vertex with a NaN coordinate is left out: every primitive that uses it is dropped by setup. */
+__global__ __launch_bounds__(256) void k_bounds(const BoundsJob* jobs, uint32_t* out_min_max)
+{
+    const BoundsJob job = jobs[blockIdx.y];
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < job.count; i += gridDim.x * blockDim.x) {
+        const float* p = reinterpret_cast<const float*>(job.vb + (size_t)i * job.stride + job.off_pos);
+        const float x = load_f32(p), y = load_f32(p + 1), z = load_f32(p + 2);
+        if (x != x || y != y || z != z) continue;
+        const uint32_t o[3] = {float_to_ordered(x), float_to_ordered(y), float_to_ordered(z)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], o[k]); hi[k] = max(hi[k], o[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], d));
+            hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], d));
+        }
+    }
+    if (lane_id() == 0) {
+        uint32_t* out = out_min_max + (size_t)blockIdx.y * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (lo[k] != 0xFFFFFFFFu) atomicMin(&out[k], lo[k]);
+            if (hi[k] != 0u) atomicMax(&out[3 + k], hi[k]);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ vertex kernel */
 
 /* a float of a uniform buffer as the frame must see it: from the pending host write when that
@@ -202,6 +242,41 @@ __device__ __forceinline__ void wave_matrices(const UniformPatch& up, const Draw
     }
 }
 
+/* True when no fragment of the draw can land inside the clamp rectangle: the eight corners of the box
+ * of its vertices, taken through the draw's matrix and the shaders' y = 1 - y, all lie beyond one and the
+ * same plane out of the rectangle's four (grown by a pixel), near and far.  A plane function is affine
+ * in the object-space position, so its largest value over the box is at a corner; a corner counts as
+ * beyond a plane only by more than TOL times the sum of the magnitudes that went into the function,
+ * which covers the rounding of this evaluation and of the vertices' own transform.  Lane k < 8 takes
+ * corner k; the answer is the same in every lane. */
+__device__ __forceinline__ bool draw_is_outside(const FrameParams& fp, const DrawStatic& d, const float* m)
+{
+    constexpr float TOL = 1.0e-5f;
+    const uint32_t lane = lane_id();
+    const float p[3] = {(lane & 1u) ? d.bounds_max[0] : d.bounds_min[0], (lane & 2u) ? d.bounds_max[1] : d.bounds_min[1],
+                        (lane & 4u) ? d.bounds_max[2] : d.bounds_min[2]};
+    float clip[4], mag[4];
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        clip[row] = fma32(m[0 * 4 + row], p[0], fma32(m[1 * 4 + row], p[1], fma32(m[2 * 4 + row], p[2], m[3 * 4 + row])));
+        mag[row] = fabsf(m[0 * 4 + row] * p[0]) + fabsf(m[1 * 4 + row] * p[1]) + fabsf(m[2 * 4 + row] * p[2]) + fabsf(m[3 * 4 + row]);
+    }
+    clip[1] = 1.0f - clip[1];
+    mag[1] = mag[1] + 1.0f;
+    const float x = clip[0], y = clip[1], z = clip[2], w = clip[3];
+    bool out[6];
+    out[0] = fma32(-fp.cull_lo_x, w, x) < -TOL * fma32(fabsf(fp.cull_lo_x), mag[3], mag[0]);
+    out[1] = fma32(fp.cull_hi_x, w, -x) < -TOL * fma32(fabsf(fp.cull_hi_x), mag[3], mag[0]);
+    out[2] = fma32(-fp.cull_lo_y, w, y) < -TOL * fma32(fabsf(fp.cull_lo_y), mag[3], mag[1]);
+    out[3] = fma32(fp.cull_hi_y, w, -y) < -TOL * fma32(fabsf(fp.cull_hi_y), mag[3], mag[1]);
+    out[4] = z < -TOL * mag[2];
+    out[5] = w - z < -TOL * (mag[3] + mag[2]);
+    bool outside = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) outside = outside || (__ballot(out[k]) & 0xFFull) == 0xFFull;
+    return outside;
+}
+
 /* One wave per chunk of 64 vertices of one draw. */
 __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 {
@@ -213,6 +288,16 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     if (chunk >= fp.n_vchunks) return;
     const Chunk c = fp.vchunks[chunk];
     const DrawStatic& d = fp.draws[c.draw];
+    float m[16], nm[9], mine;
+    const bool cullable = d.has_bounds != 0u;
+    if (cullable) {
+        /* a draw with a box is tested before anything of it is fetched: a culled one costs its waves
+         * the matrices and nothing else, and setup skips its primitives */
+        wave_matrices(up, d, m, nm, mine);
+        const bool outside = draw_is_outside(fp, d, m);
+        if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = outside ? 0u : 1u;
+        if (outside) return;
+    }
     /* the vertex's attributes are requested first: they do not depend on the matrices, whose
      * construction (loads, multiply-adds, broadcasts) then runs under their latency */
     const uint32_t v = c.first + lane_id();
@@ -231,8 +316,10 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
             nrm[0] = load_f32(q); nrm[1] = load_f32(q + 1); nrm[2] = load_f32(q + 2);
         }
     }
-    float m[16], nm[9], mine;
-    wave_matrices(up, d, m, nm, mine);
+    if (!cullable) {
+        wave_matrices(up, d, m, nm, mine);
+        if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = 1u;
+    }
     if (c.first == 0 && lane_id() < 16u) fp.derived[c.draw].clip_m[lane_id()] = mine;
     if (!live) return;
     /* vertex shader position: M * vec4(pos,1), then the reference's clip-space y = 1 - y
@@ -412,6 +499,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_tchunks) return;
     const Chunk c = fp.tchunks[chunk];
+    if (!fp.derived[c.draw].visible) return; /* the vertex kernel found the draw's box outside what this device renders */
     const DrawStatic& d = fp.draws[c.draw];
     const uint32_t lane = lane_id();
     const uint32_t tri = c.first + lane;
@@ -1253,8 +1341,10 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
     uint32_t tile, utx, uty;
     if (fp.shard_count == 1) {
-        rows_of_eight(blockIdx.x, fp.tiles_x, magic, utx, uty);
-        if (uty >= fp.tiles_y) return; /* padding of the grid */
+        /* the grid covers the tiles the render area touches */
+        rows_of_eight(blockIdx.x, fp.grid_w, magic, utx, uty);
+        if (uty >= fp.grid_h) return; /* padding of the grid */
+        utx += fp.grid_x0; uty += fp.grid_y0;
         tile = uty * fp.tiles_x + utx;
     } else {
         tile = blockIdx.x * fp.shard_count + fp.shard_index; /* this shard's tiles, in order */
@@ -1369,6 +1459,12 @@ void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n
     hipLaunchKernelGGL(k_index_range, dim3(64, n_jobs), dim3(256), 0, s, jobs, out_max);
 }
 
+void launch_bounds(const BoundsJob* jobs, uint32_t* out_min_max, uint32_t n_jobs, hipStream_t s)
+{
+    if (!n_jobs) return;
+    hipLaunchKernelGGL(k_bounds, dim3(64, n_jobs), dim3(256), 0, s, jobs, out_min_max);
+}
+
 void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s)
 {
     const uint32_t blocks = (fp.n_vchunks + 3) / 4;
@@ -1389,8 +1485,9 @@ void launch_tile(const FrameParams& fp, hipStream_t s)
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     const uint32_t mine = n_tiles > fp.shard_index ? (n_tiles - fp.shard_index + fp.shard_count - 1) / fp.shard_count : 0;
     if (!mine) return;
-    const uint32_t grid = fp.shard_count == 1 ? rows_of_eight_grid(fp.tiles_x, fp.tiles_y) : mine;
-    const uint32_t magic = rows_of_eight_magic(fp.tiles_x);
+    if (fp.shard_count == 1 && (!fp.grid_w || !fp.grid_h)) return; /* empty render area */
+    const uint32_t grid = fp.shard_count == 1 ? rows_of_eight_grid(fp.grid_w, fp.grid_h) : mine;
+    const uint32_t magic = rows_of_eight_magic(fp.shard_count == 1 ? fp.grid_w : fp.tiles_x);
     if (fp.samples == 4) hipLaunchKernelGGL(k_tile<4>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
     else hipLaunchKernelGGL(k_tile<1>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
 }

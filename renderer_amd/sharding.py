@@ -7,7 +7,12 @@ neither of which needs a collective while rendering:
   * sort-first tiles: rank k renders the 32x32 tiles t with t % world == k of ONE frame
     (rnd_cmd_set_tile_shard); geometry is replicated, and only the finished colour image
     is exchanged -- one all_gather of equal-sized slabs, each holding the tiles one rank owns,
-    which are then put back in place.
+    which are then put back in place;
+  * sort-first bands: rank k renders a band of whole rows of tiles of ONE frame, given to the
+    library as the pass's render area and scissor.  The library then launches only the band's
+    tiles and skips every draw whose box of vertices misses the band, so geometry work is
+    divided as well as pixel work; the exchange is one all_gather of the bands, which are
+    contiguous rows of the image.
 """
 import numpy as np
 
@@ -78,6 +83,52 @@ def gather_frame(local_image, dist, world, rank=None):
     slabs = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
     dist.all_gather_into_tensor(slabs, slab)  # rank r's slab lands at [r * slots, (r + 1) * slots)
     return unpack_tiles(slabs.view((world,) + tuple(slab.shape)), w, h)
+
+
+def band_rows(height, rank, world):
+    """Pixel rows [y0, y1) of rank `rank`: the rows of tiles are split as evenly as whole rows of
+    tiles allow (the first `rows % world` ranks get one more); a rank may get none (y0 == y1)."""
+    tile_rows = (height + TILE - 1) // TILE
+    base, extra = divmod(tile_rows, world)
+    first = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    return min(first * TILE, height), min((first + count) * TILE, height)
+
+
+def band_scene(scene, rank, world):
+    """A copy of the scene whose render area and scissor are cut down to the band of `rank`."""
+    import copy
+    y0, y1 = band_rows(scene.height, rank, world)
+    sc = copy.copy(scene)
+    ax, ay, aw, ah = scene.area if scene.area is not None else (0, 0, scene.width, scene.height)
+    sx, sy, sw, sh = scene.scissor
+    by0, by1 = max(ay, y0), min(ay + ah, y1)
+    sc.area = (ax, by0, aw, max(by1 - by0, 0))
+    cy0, cy1 = max(sy, y0), min(sy + sh, y1)
+    sc.scissor = (sx, cy0, sw, max(cy1 - cy0, 0))
+    return sc
+
+
+def gather_bands(band, dist, world, height):
+    """all_gather of the bands: `band` is this rank's rows (rows x W x C uint8 torch tensor on the
+    backend's device).  Every rank returns the full H x W x C frame.  When the rows of tiles divide
+    evenly the bands land in the frame directly; otherwise each is padded to the tallest band and the
+    frame is put together from the valid rows.  Bytes on the wire per rank: its band sent, the frame received."""
+    import torch
+    spans = [band_rows(height, r, world) for r in range(world)]
+    tallest = max(y1 - y0 for y0, y1 in spans)
+    w, c = band.shape[1], band.shape[2]
+    if all(y1 - y0 == tallest for y0, y1 in spans):
+        frame = torch.empty((height, w, c), dtype=band.dtype, device=band.device)
+        dist.all_gather_into_tensor(frame.view(-1), band.contiguous().view(-1))
+        return frame
+    mine = band
+    if band.shape[0] < tallest:
+        mine = band.new_zeros((tallest, w, c))
+        mine[:band.shape[0]] = band
+    slabs = torch.empty((world, tallest, w, c), dtype=band.dtype, device=band.device)
+    dist.all_gather_into_tensor(slabs.view(-1), mine.contiguous().view(-1))
+    return torch.cat([slabs[r, :y1 - y0] for r, (y0, y1) in enumerate(spans)])
 
 
 def max_over_ranks(value, dist, device="cpu"):

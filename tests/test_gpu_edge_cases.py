@@ -390,6 +390,85 @@ def test_tile_shards_compose_the_frame(device, oracle, shards):
     assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
 
 
+@pytest.mark.parametrize("bands", [2, 3, 8])
+@pytest.mark.parametrize("samples", [1, 4])
+def test_bands_compose_the_frame(device, oracle, bands, samples):
+    """Sort-first sharding by render area: band k of n is rows of whole tiles given as the pass's render
+    area and scissor.  Inside its band a device's pixels are the unsharded frame's, outside it touches
+    nothing, and it skips the draws that lie wholly in other bands."""
+    from renderer_amd import sharding
+    sc = scenes.instanced_spheres(300, 200, 6, 5, 3, 5, tex_size=64)
+    sc.samples = samples
+    for p in sc.pipelines:
+        p["samples"] = samples
+    full_c, full_d = check(sc, device, oracle)
+    acc_c, acc_d = np.zeros_like(full_c), np.zeros_like(full_d)
+    kept = []
+    for k in range(bands):
+        y0, y1 = sharding.band_rows(sc.height, k, bands)
+        r = SceneRunner(sharding.band_scene(sc, k, bands), device)
+        try:
+            c, d = r.render()
+            kept.append(r.cmd.visible_draws())
+        finally:
+            r.destroy()
+        acc_c[y0:y1], acc_d[y0:y1] = c[y0:y1], d[y0:y1]
+        assert (c[:y0] == 0).all() and (c[y1:] == 0).all() and (d[:y0] == 0).all() and (d[y1:] == 0).all()
+    assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
+    assert sum(kept) < bands * len(sc.draws)  # some draws were skipped somewhere ...
+    assert sum(kept) >= len(sc.draws)         # ... and every draw was kept by the band(s) it shows in
+    if bands == 8:  # seven rows of tiles: bands of one row (two or three of the five rows of spheres), the last band empty
+        assert max(kept) <= len(sc.draws) * 2 // 3 and kept[-1] == 0
+
+
+def test_draws_outside_the_frustum_are_skipped(device, oracle):
+    """Draws pushed wholly beyond each of the six planes are skipped; draws that straddle a plane, sit in a
+    corner, or enclose the whole frustum are kept; the frame is the oracle's either way."""
+    sc = scenes.instanced_spheres(256, 160, 3, 2, 1, 11, tex_size=32)
+    base = sc.draws[0]
+    n_inside = len(sc.draws)
+
+    def add(tx, ty, tz, s):
+        m = hm.scale(hm.translate(hm.identity(), [tx, ty, tz]), [s, s, s])
+        d = dict(base)
+        d["push"] = scenes.push_block([0.9, 0.5, 0.2, 1.0], m)
+        sc.draws.append(d)
+
+    outside = [(-40.0, 1.0, 0.0, 1.0), (40.0, 1.0, 0.0, 1.0), (0.0, 41.0, 0.0, 1.0), (0.0, -39.0, 0.0, 1.0),
+               (0.0, 1.0, -6.0, 1.0), (0.0, 1.0, 300.0, 1.0)]
+    kept = [(-3.2, 1.0, 0.0, 1.0), (0.0, 3.0, 0.0, 0.7), (0.0, 1.0, -1.6, 0.5), (3.0, 3.0, 0.5, 0.8), (0.0, 1.0, 0.0, 500.0),
+            (0.0, 1.0, 99.0, 3.0)]
+    for t in outside + kept:
+        add(*t)
+    r = SceneRunner(sc, device)
+    try:
+        color, depth = r.render()
+        visible = r.cmd.visible_draws()
+    finally:
+        r.destroy()
+    oc, od, _ = oracle.render_scene(sc, threads=8)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)
+    assert visible == n_inside + len(kept)
+
+
+def test_scissored_pass_skips_draws_and_tiles_outside(device, oracle):
+    """A scissor inside the render area inside the target, none aligned to tiles: draws outside the scissor
+    are skipped, pixels inside the area but outside the scissor are cleared, pixels outside the area are
+    left alone."""
+    sc = scenes.instanced_spheres(320, 224, 8, 6, 2, 3, tex_size=32)
+    sc.area = (37, 41, 230, 150)
+    sc.scissor = (70, 60, 100, 75)
+    r = SceneRunner(sc, device)
+    try:
+        color, depth = r.render()
+        visible = r.cmd.visible_draws()
+    finally:
+        r.destroy()
+    oc, od, _ = oracle.render_scene(sc, threads=8)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)
+    assert 0 < visible < len(sc.draws) // 2
+
+
 def test_resubmission_is_idempotent(device):
     sc = helpers.soup_scene(200, 150, 2000, 77, depth_levels=2, n_draws=7)
     r = SceneRunner(sc, device)

@@ -68,6 +68,48 @@ def test_pack_and_unpack_tiles(wh, world):
     assert torch.equal(sharding.unpack_tiles(torch.stack(slabs), w, h), full)
 
 
+@pytest.mark.parametrize("height", [32, 200, 1080, 4320, 31])
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 64])
+def test_band_rows_cover_the_frame(height, world):
+    """Bands are whole rows of tiles, in rank order, disjoint, cover every row, and differ by at most one row of tiles."""
+    spans = [sharding.band_rows(height, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == height
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0 and a0 <= a1
+    assert all(y0 % 32 == 0 or y0 == height for y0, _ in spans)
+    rows = [(y1 - y0 + 31) // 32 for y0, y1 in spans]
+    assert max(rows) - min(rows) <= 1
+
+
+def _band_worker(rank, world, height, width, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    full = torch.from_numpy(np.random.RandomState(9).randint(0, 256, (height, width, 4)).astype(np.uint8))
+    y0, y1 = sharding.band_rows(height, rank, world)
+    frame = sharding.gather_bands(full[y0:y1].clone(), dist, world, height)
+    np.save(os.path.join(out_dir, "b_%d.npy" % rank), np.array([bool(torch.equal(frame, full))]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 128), (2, 100), (3, 200)])
+def test_band_gather_over_gloo(tmp_path, world, height):
+    """Even bands land in the frame directly, uneven ones through padded slabs: every rank ends with the frame."""
+    import torch.multiprocessing as mp
+    mp.spawn(_band_worker, args=(world, height, 96, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(str(tmp_path / ("b_%d.npy" % r)))[0]
+
+
+def test_band_scene_cuts_area_and_scissor():
+    from renderer_amd import scenes
+    sc = scenes.Scene(300, 200)
+    sc.scissor = (10, 50, 200, 100)
+    b = sharding.band_scene(sc, 1, 2)  # rows of tiles: 7 -> 4 + 3: band 1 = pixel rows [128, 200)
+    assert b.area == (0, 128, 300, 72) and b.scissor == (10, 128, 200, 22)
+    assert sc.area == (0, 0, 300, 200)  # the original is untouched
+
+
 def test_owner_map_matches_kernel_rule():
     """tile t = ty * tiles_x + tx belongs to rank t % world; every pixel has exactly one owner."""
     own = sharding.tile_owner_map(100, 70, 3)
