@@ -114,6 +114,7 @@ def main():
                     help="single-GPU rehearsal of the tiles mode (or, with --mode bands, the bands mode): render only what "
                          "rank --shard-rank of N would own, no exchange")
     ap.add_argument("--shard-rank", type=int, default=0, help="which rank's share --one-shard-of renders")
+    ap.add_argument("--no-overlap", action="store_true", help="bands mode: gather every frame before the next is rendered")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=20)
     args = ap.parse_args()
@@ -126,7 +127,7 @@ def main():
     # BENCH_BACKEND=gloo rehearses the multi-rank paths on a box with fewer GPUs than ranks: the ranks
     # share the GPUs that are there and the exchange goes through host memory (numbers mean nothing)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and args.mode != "views"):  # a one-rank launch of a sharded mode runs the same exchange code
         import torch
         import torch.distributed as dist
         if backend == "nccl":
@@ -145,13 +146,16 @@ def main():
         for p in scene.pipelines:
             p["samples"] = args.samples
     bands = args.mode == "bands"
-    tiles_mode = args.mode in ("tiles", "bands") and world > 1
+    tiles_mode = args.mode in ("tiles", "bands") and dist is not None
     whole_scene = scene
-    if bands and (world > 1 or args.one_shard_of > 1):
+    if bands and (tiles_mode or args.one_shard_of > 1):
         from renderer_amd import sharding
-        scene = sharding.band_scene(scene, *((rank, world) if world > 1 else (args.shard_rank, args.one_shard_of)))
-    # the sharded modes gather every frame before the next starts: one image is all they can use
-    run = SceneRunner(scene, ordinal=local_rank, frames_in_flight=1 if tiles_mode else args.frames_in_flight)
+        scene = sharding.band_scene(scene, *((rank, world) if tiles_mode else (args.shard_rank, args.one_shard_of)))
+    # Bands over RCCL are pipelined: while the bands of frame i are exchanged, frame i + 1 is rendered into the
+    # other image.  The tiles mode (and any run over gloo) gathers every frame before the next starts.
+    pipelined = tiles_mode and bands and backend == "nccl" and args.frames_in_flight >= 2 and not args.no_overlap
+    run = SceneRunner(scene, ordinal=local_rank,
+                      frames_in_flight=2 if pipelined else 1 if tiles_mode else args.frames_in_flight)
     if tiles_mode and not bands:
         run.cmd.set_tile_shard(rank, world)
     elif args.one_shard_of > 1 and not bands:
@@ -198,13 +202,68 @@ def main():
             gather_s[0] += time.perf_counter() - t_g
             return frame
 
+    finish = None
+    if pipelined:
+        # The exchange reads each image's band where the library rendered it (no copy-out), as equal-sized slabs
+        # of rows (sharding.band_send_rows).  Order per image: render (library stream) -> fence -> all_gather
+        # (RCCL's stream) -> host wait on it before the image is rendered into again.
+        s0, tallest = sharding.band_send_rows(scene.height, rank, world)
+        pitch = scene.width * 4
+        src = [sharding.device_bytes(t.color_device_ptr, scene.height * pitch)[s0 * pitch:(s0 + tallest) * pitch]
+               for t in run.targets]
+        slabs = [torch.empty((world, tallest, scene.width, 4), dtype=torch.uint8, device="cuda") for _ in run.targets]
+        fences = [api.Fence(run.dev) for _ in run.targets]
+        work = [None] * len(run.targets)
+        waiting = [None]  # image whose frame is rendered (or rendering) and not yet exchanged
+        last_frame = [None]
+
+        def exchange(img):
+            fences[img].wait()
+            work[img] = dist.all_gather_into_tensor(slabs[img].view(-1), src[img], async_op=True)
+
+        def collect(img):
+            """The frame of image img's last exchange, once it is done (None if there was none)."""
+            if work[img] is None:
+                return None
+            work[img].wait()
+            work[img] = None
+            frame = sharding.compose_bands(slabs[img], scene.height)
+            torch.cuda.current_stream().synchronize()
+            return frame
+
+        def step(i):  # noqa: F811
+            img = run.next_image
+            f = collect(img)
+            if f is not None:
+                last_frame[0] = f
+            run.set_ubo(0, ubos[i])
+            run.next_image = (img + 1) % run.frames_in_flight
+            run.dev.submit(run.cmds[img], fences[img])
+            if waiting[0] is not None:
+                exchange(waiting[0])
+            waiting[0] = img
+
+        def finish():
+            if waiting[0] is not None:
+                exchange(waiting[0])
+                waiting[0] = None
+            for img in range(len(run.targets)):
+                f = collect(img)
+                if f is not None:
+                    last_frame[0] = f
+            return last_frame[0]
+
     for i in range(args.warmup):
         step(i)
+    if finish:
+        finish()
     sync()
     gather_s[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if finish:
+        finish()
     run.dev.wait_idle()
     if dist is not None:
         torch.cuda.synchronize()
@@ -216,11 +275,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    gather_ms = gather_s[0] / args.steps * 1e3 if tiles_mode else None
+    gather_ms = gather_s[0] / args.steps * 1e3 if tiles_mode and not pipelined else None
     tiles_check = None
     if tiles_mode:
         # the gathered frame against the same frame rendered whole on this rank
-        frame = step(0).cpu().numpy()
+        if pipelined:
+            step(0)
+            frame = finish().cpu().numpy()
+        else:
+            frame = step(0).cpu().numpy()
         whole = SceneRunner(whole_scene, ordinal=local_rank)
         whole.set_ubo(0, ubos[0])
         color, _ = whole.render()
@@ -281,7 +344,8 @@ def main():
             "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, %d sample%s/pixel" % (
                 scene.name, scene.width, scene.height, scene.triangle_count(), len(scene.draws), scene.samples,
                 "" if scene.samples == 1 else "s"),
-                "sharding": ("%s of one frame over %d GPUs + RCCL all_gather" % (args.mode, world)) if tiles_mode
+                "sharding": ("%s of one frame over %d GPUs + RCCL all_gather%s" % (
+                    args.mode, world, ", exchange of a frame overlapped with the next frame's rendering" if pipelined else "")) if tiles_mode
                 else ("rehearsal: the %s of rank %d of %d only" % (args.mode if bands else "tiles", args.shard_rank, args.one_shard_of)) if args.one_shard_of > 1
                 else ("one view per GPU, %d GPUs" % world), "frames_in_flight": run.frames_in_flight,
                 "seed": scene.seed},

@@ -210,24 +210,30 @@ __device__ __forceinline__ float lane_value(float v, int lane)
  * shader uses mvp alone (dummy.vert.glsl:22).  Lane k < 16 computes element k of the first product,
  * lane 16 + k element k of the second, each as the same four-term multiply-add chain a scalar
  * implementation runs; the results are then broadcast. */
-__device__ __forceinline__ void wave_matrices(const UniformPatch& up, const DrawStatic& d, float* clip_m, float* nrm_m, float& my_element)
+__device__ __forceinline__ float wave_matrix_element(const UniformPatch& up, const DrawStatic& d)
 {
     const uint32_t lane = lane_id();
     const uint32_t k = lane & 15u, row = k & 3u, col = k >> 2;
-    float acc;
-    if (d.shader == 0) {
-        acc = uniform_read(up, d.ubo + 64 + k);
-    } else {
-        const float* a = d.ubo + ((lane & 16u) ? 48 : 64); /* model : mvp */
-        const float* b = d.push + 4 + col * 4;
-        acc = uniform_read(up, a + 0 * 4 + row) * b[0];
-        acc = fma32(uniform_read(up, a + 1 * 4 + row), b[1], acc);
-        acc = fma32(uniform_read(up, a + 2 * 4 + row), b[2], acc);
-        acc = fma32(uniform_read(up, a + 3 * 4 + row), b[3], acc);
-    }
-    my_element = acc;
+    if (d.shader == 0) return uniform_read(up, d.ubo + 64 + k);
+    const float* a = d.ubo + ((lane & 16u) ? 48 : 64); /* model : mvp */
+    const float* b = d.push + 4 + col * 4;
+    float acc = uniform_read(up, a + 0 * 4 + row) * b[0];
+    acc = fma32(uniform_read(up, a + 1 * 4 + row), b[1], acc);
+    acc = fma32(uniform_read(up, a + 2 * 4 + row), b[2], acc);
+    acc = fma32(uniform_read(up, a + 3 * 4 + row), b[3], acc);
+    return acc;
+}
+
+/* object space -> clip space, from lanes 0..15 */
+__device__ __forceinline__ void wave_clip_matrix(float element, float* clip_m)
+{
 #pragma unroll
-    for (int i = 0; i < 16; ++i) clip_m[i] = lane_value(acc, i);
+    for (int i = 0; i < 16; ++i) clip_m[i] = lane_value(element, i);
+}
+
+/* the normal matrix, from lanes 16..26 */
+__device__ __forceinline__ void wave_normal_matrix(const DrawStatic& d, float element, float* nrm_m)
+{
     if (d.shader == 0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) nrm_m[i] = 0.0f;
@@ -235,9 +241,9 @@ __device__ __forceinline__ void wave_matrices(const UniformPatch& up, const Draw
         float mt[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) mt[i] = 0.0f;
-        mt[0] = lane_value(acc, 16); mt[1] = lane_value(acc, 17); mt[2] = lane_value(acc, 18);
-        mt[4] = lane_value(acc, 20); mt[5] = lane_value(acc, 21); mt[6] = lane_value(acc, 22);
-        mt[8] = lane_value(acc, 24); mt[9] = lane_value(acc, 25); mt[10] = lane_value(acc, 26);
+        mt[0] = lane_value(element, 16); mt[1] = lane_value(element, 17); mt[2] = lane_value(element, 18);
+        mt[4] = lane_value(element, 20); mt[5] = lane_value(element, 21); mt[6] = lane_value(element, 22);
+        mt[8] = lane_value(element, 24); mt[9] = lane_value(element, 25); mt[10] = lane_value(element, 26);
         normal_matrix(mt, nrm_m);
     }
 }
@@ -293,7 +299,8 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     if (cullable) {
         /* a draw with a box is tested before anything of it is fetched: a culled one costs its waves
          * the matrices and nothing else, and setup skips its primitives */
-        wave_matrices(up, d, m, nm, mine);
+        mine = wave_matrix_element(up, d);
+        wave_clip_matrix(mine, m);
         const bool outside = draw_is_outside(fp, d, m);
         if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = outside ? 0u : 1u;
         if (outside) return;
@@ -317,9 +324,11 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
         }
     }
     if (!cullable) {
-        wave_matrices(up, d, m, nm, mine);
+        mine = wave_matrix_element(up, d);
+        wave_clip_matrix(mine, m);
         if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = 1u;
     }
+    wave_normal_matrix(d, mine, nm);
     if (c.first == 0 && lane_id() < 16u) fp.derived[c.draw].clip_m[lane_id()] = mine;
     if (!live) return;
     /* vertex shader position: M * vec4(pos,1), then the reference's clip-space y = 1 - y

@@ -131,6 +131,39 @@ def gather_bands(band, dist, world, height):
     return torch.cat([slabs[r, :y1 - y0] for r, (y0, y1) in enumerate(spans)])
 
 
+def band_send_rows(height, rank, world):
+    """Rows [s0, s0 + tallest) of rank `rank`'s own image that it contributes to an exchange of equal-sized
+    slabs straight out of the image: `tallest` rows (the tallest band's height) that contain its band.  A rank
+    with a shorter band sends neighbouring rows along, which compose_bands drops."""
+    tallest = max(b - a for a, b in (band_rows(height, r, world) for r in range(world)))
+    y0, _ = band_rows(height, rank, world)
+    return min(y0, height - tallest), tallest
+
+
+def compose_bands(slabs, height):
+    """The frame from the gathered slabs (world, tallest, W, C), slab r being rank r's band_send_rows: a view
+    when the bands are all equally tall, else a copy of every slab's valid rows."""
+    import torch
+    world, tallest = slabs.shape[0], slabs.shape[1]
+    spans = [band_rows(height, r, world) for r in range(world)]
+    if all(b - a == tallest for a, b in spans):
+        return slabs.view(height, slabs.shape[2], slabs.shape[3])
+    return torch.cat([slabs[r, a - min(a, height - tallest):][:b - a] for r, (a, b) in enumerate(spans)])
+
+
+class _DeviceMemory:
+    """Device memory that is not torch's, described the way torch.as_tensor understands."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_bytes(ptr, nbytes):
+    """A uint8 torch tensor over nbytes of device memory at ptr (no copy; the memory stays the owner's)."""
+    import torch
+    return torch.as_tensor(_DeviceMemory(ptr, nbytes), device="cuda")
+
+
 def max_over_ranks(value, dist, device="cpu"):
     """Largest value over the ranks (the benchmark's elapsed time)."""
     import torch

@@ -88,11 +88,20 @@ def _band_worker(rank, world, height, width, port, out_dir):
     full = torch.from_numpy(np.random.RandomState(9).randint(0, 256, (height, width, 4)).astype(np.uint8))
     y0, y1 = sharding.band_rows(height, rank, world)
     frame = sharding.gather_bands(full[y0:y1].clone(), dist, world, height)
-    np.save(os.path.join(out_dir, "b_%d.npy" % rank), np.array([bool(torch.equal(frame, full))]))
+    ok = bool(torch.equal(frame, full))
+    # the exchange straight out of each rank's own image: right inside its band, anything elsewhere
+    image = torch.full_like(full, 77)
+    image[y0:y1] = full[y0:y1]
+    s0, tallest = sharding.band_send_rows(height, rank, world)
+    assert 0 <= s0 <= y0 and y1 <= s0 + tallest <= height
+    slabs = torch.empty((world, tallest, width, 4), dtype=torch.uint8)
+    dist.all_gather_into_tensor(slabs.view(-1), image[s0:s0 + tallest].reshape(-1))
+    ok = ok and bool(torch.equal(sharding.compose_bands(slabs, height), full))
+    np.save(os.path.join(out_dir, "b_%d.npy" % rank), np.array([ok]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height", [(2, 128), (2, 100), (3, 200)])
+@pytest.mark.parametrize("world,height", [(2, 128), (2, 100), (3, 200), (3, 270)])
 def test_band_gather_over_gloo(tmp_path, world, height):
     """Even bands land in the frame directly, uneven ones through padded slabs: every rank ends with the frame."""
     import torch.multiprocessing as mp
