@@ -51,11 +51,19 @@ struct __attribute__((aligned(16))) ShadeTables {
 constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   /* primitive slot (submission number) */
 constexpr uint32_t ENTRY_SUB_SHIFT = 28;      /* bits 28..30: fan index of a clipped primitive's triangle */
 constexpr uint32_t FLAG_CLIPPED = 0x80000000u;
+constexpr int FRAG_BOX_W = 4, FRAG_BOX_H = 2, FRAG_MAX = 3;
 constexpr uint32_t MAX_FAN = 7;               /* a triangle clipped by 6 planes has at most 9 corners */
 
 /* One triangle in a tile's list: 16 bytes, read with one dwordx4 per lane.
  * Unclipped: a,b,c index svtx[] and are ordered so the area is positive.
- * Clipped (FLAG_CLIPPED): a indexes clip_tris[]. */
+ * Clipped (FLAG_CLIPPED): a indexes clip_tris[].
+ * Fragments (FLAG_CLIPPED clear, bits 28..30 = n in 1..3): setup has already rasterised the triangle, whose box
+ * is at most FRAG_BOX_W x FRAG_BOX_H pixels; the entry holds its n covered pixels and their depths:
+ *   a = D24 of fragment 0 | (x0 & 63) << 24 | (y0 & 3) << 30      (x0, y0: first pixel of the box)
+ *   b = D24 of fragment 1 | mask << 24                             (bit dy * FRAG_BOX_W + dx: pixel (x0+dx, y0+dy) covered)
+ *   c = D24 of fragment 2 | ((y0 >> 2) & 15) << 24
+ * Fragments are numbered in the order of the mask's set bits.  Positions are kept modulo 64, which is
+ * enough for a tile to find those of the box's pixels that are its own. */
 struct TileEntry {
     uint32_t a, b, c;
     uint32_t slot_flags;

@@ -500,9 +500,65 @@ __device__ __forceinline__ void clip_primitive(const FrameParams& fp, const Draw
     }
 }
 
+/* Rasterises a triangle whose box [x0,x1] x [y0,y1] is at most FRAG_BOX_W x FRAG_BOX_H pixels, here in
+ * setup, with the integers and the depth arithmetic of the tile kernel's walk (EdgeSetup): the edge
+ * functions at the box's first pixel centre, stepped by a constant per pixel, top-left rule as a bias of
+ * one, depth from the unbiased values of edges 1 and 2.  Corners a, b, c in positive-area order.  Returns
+ * the number of covered pixels; mask has bit dy * FRAG_BOX_W + dx set for each, d0..d2 are the depth words of
+ * the first three set bits. */
+struct MicroFragments {
+    uint32_t count, mask, d0, d1, d2;
+};
+
+__device__ __forceinline__ MicroFragments micro_fragments(uint32_t depth_test, int32_t ax, int32_t ay, int32_t bx, int32_t by,
+                                                          int32_t cx, int32_t cy, float za, float zb, float zc, float inv_area,
+                                                          int x0, int y0, int x1, int y1)
+{
+    const int32_t dx0 = cx - bx, dy0 = cy - by;
+    const int32_t dx1 = ax - cx, dy1 = ay - cy;
+    const int32_t dx2 = bx - ax, dy2 = by - ay;
+    const int32_t bias0 = owns_edge(bx, by, cx, cy) ? 0 : 1;
+    const int32_t bias1 = owns_edge(cx, cy, ax, ay) ? 0 : 1;
+    const int32_t bias2 = owns_edge(ax, ay, bx, by) ? 0 : 1;
+    const int32_t px = x0 * 256 + 128, py = y0 * 256 + 128;
+    const int32_t r0 = __mul24(dx0, py - by) - __mul24(dy0, px - bx);
+    const int32_t r1 = __mul24(dx1, py - cy) - __mul24(dy1, px - cx);
+    const int32_t r2 = __mul24(dx2, py - ay) - __mul24(dy2, px - ax);
+    const float z0 = za, dz1 = zb - za, dz2 = zc - za;
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+    uint32_t count = 0, mask = 0, d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+    for (int j = 0; j < FRAG_BOX_H; ++j) {
+#pragma unroll
+        for (int i = 0; i < FRAG_BOX_W; ++i) {
+            /* one pixel right: -256 dy; one pixel down: +256 dx */
+            const int32_t e0 = r0 - i * (dy0 << 8) + j * (dx0 << 8);
+            const int32_t e1 = r1 - i * (dy1 << 8) + j * (dx1 << 8);
+            const int32_t e2 = r2 - i * (dy2 << 8) + j * (dx2 << 8);
+            if (i < w && j < h && (((e0 - bias0) | (e1 - bias1) | (e2 - bias2)) >= 0)) {
+                const float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
+                const float z = fma32(b2, dz2, fma32(b1, dz1, z0));
+                const uint32_t d = depth_test ? depth24(z) : 0u;
+                d0 = count == 0 ? d : d0;
+                d1 = count == 1 ? d : d1;
+                d2 = count == 2 ? d : d2;
+                mask |= 1u << (j * FRAG_BOX_W + i);
+                ++count;
+            }
+        }
+    }
+    return MicroFragments{count, mask, d0, d1, d2};
+}
+
 /* One wave per chunk of 64 primitives of one draw: fetch, classify, cull and orient, bin; then
  * clip the few that need it. */
-__global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
+#ifndef SETUP_WAVES
+#define SETUP_WAVES 8
+#endif
+#ifndef RND_FRAG_ENTRIES
+#define RND_FRAG_ENTRIES 1
+#endif
+__global__ __launch_bounds__(256, SETUP_WAVES) void k_setup(FrameParams fp)
 {
     __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -535,9 +591,29 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
                 PrimRec pr = {v0, v1, v2, c.draw};
                 if (!fp.direct_index) fp.prim_rec[slot] = pr;
                 /* what rasterisation needs: corners ordered for positive area */
-                e.a = d.svtx_base + pf.idx[t.corner[0]];
-                e.b = d.svtx_base + pf.idx[t.corner[1]];
-                e.c = d.svtx_base + pf.idx[t.corner[2]];
+                /* orienting swaps corners 1 and 2 or nothing (selects, not an indexed read of pf.idx, which
+                 * would put the whole fetch record in private memory) */
+                const bool swapped = t.corner[1] == 2;
+                e.a = d.svtx_base + pf.idx[0];
+                e.b = d.svtx_base + (swapped ? pf.idx[2] : pf.idx[1]);
+                e.c = d.svtx_base + (swapped ? pf.idx[1] : pf.idx[2]);
+                /* A triangle of a few pixels is rasterised here and now, with its corners in registers: its
+                 * entry then carries fragments, and the tile kernel neither gathers its vertices nor walks
+                 * its box.  One that covers no pixel centre gets no entry at all. */
+                const int ext = max(max(t.x[0], max(t.x[1], t.x[2])) - min(t.x[0], min(t.x[1], t.x[2])),
+                                    max(t.y[0], max(t.y[1], t.y[2])) - min(t.y[0], min(t.y[1], t.y[2])));
+                if (RND_FRAG_ENTRIES && fp.samples == 1 && x1 - x0 < FRAG_BOX_W && y1 - y0 < FRAG_BOX_H && ext < (1 << 14) && !RND_PROBE(fp, 32u)) {
+                    const MicroFragments mf = micro_fragments(fp.depth_test, t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2],
+                                                              t.z[0], t.z[1], t.z[2], t.inv_area, x0, y0, x1, y1);
+                    if (mf.count == 0) {
+                        valid = false;
+                    } else if (mf.count <= (uint32_t)FRAG_MAX) {
+                        e.a = mf.d0 | ((uint32_t)(x0 & 63) << 24) | ((uint32_t)(y0 & 3) << 30);
+                        e.b = mf.d1 | (mf.mask << 24);
+                        e.c = mf.d2 | ((uint32_t)((y0 >> 2) & 15) << 24);
+                        e.slot_flags = slot | (mf.count << ENTRY_SUB_SHIFT);
+                    }
+                }
             }
         }
     }
@@ -741,6 +817,34 @@ __device__ __forceinline__ void raster_wave(const FrameParams& fp, const TileCtx
     for (int by = y0; by <= y1; by += 8) for (int bx = x0; bx <= x1; bx += 8) {
         const int x = bx + lx, y = by + ly;
         if (x <= x1 && y <= y1) es.pixel(tc, x, y);
+    }
+}
+
+/* An entry whose triangle setup has already rasterised: its fragments go straight to the tile's words.
+ * Positions are modulo 64; a pixel is this tile's when its offset from the tile's first pixel, modulo 64, is
+ * below 32 in both directions (the box is a few pixels, so no other pixel of it can alias). */
+__device__ __forceinline__ bool entry_holds_fragments(const TileEntry& e)
+{
+    return (e.slot_flags & (FLAG_CLIPPED | (7u << ENTRY_SUB_SHIFT))) - 1u < (FLAG_CLIPPED - 1u); /* sub != 0 and not clipped */
+}
+
+__device__ __forceinline__ void emit_fragments(const FrameParams& fp, const TileCtx& tc, const TileEntry& e)
+{
+    const uint32_t slot = e.slot_flags & SLOT_MASK;
+    const uint32_t ord = fp.depth_less ? slot : ~slot;
+    const unsigned long long payload = (unsigned long long)ord << 8;
+    const uint32_t bx = (e.a >> 24) & 63u, by = (e.a >> 30) | (((e.c >> 24) & 15u) << 2);
+    const uint32_t relx = (bx - (uint32_t)tc.px0) & 63u, rely = (by - (uint32_t)tc.py0) & 63u;
+    uint32_t mask = e.b >> 24;
+    const uint32_t depth[FRAG_MAX] = {e.a & 0xFFFFFFu, e.b & 0xFFFFFFu, e.c & 0xFFFFFFu};
+#pragma unroll
+    for (int k = 0; k < FRAG_MAX; ++k) {
+        if (!mask) break;
+        const uint32_t bit = (uint32_t)__ffs((int)mask) - 1u;
+        mask &= mask - 1u;
+        const uint32_t x = (relx + (bit & (FRAG_BOX_W - 1))) & 63u, y = (rely + bit / FRAG_BOX_W) & 63u;
+        if (x < (uint32_t)TILE_W && y < (uint32_t)TILE_H)
+            atomicMin(&tc.keys[y * TILE_W + x], ((unsigned long long)depth[k] << 40) | payload);
     }
 }
 
@@ -1271,6 +1375,7 @@ __device__ __forceinline__ void raster_stream(const FrameParams& fp, const TileC
         TileEntry e0;
         const uint32_t i0 = entry_of(0), i1 = entry_of(TILE_THREADS);
         h_cur = i0 < n && fetch(i0, e0);
+        if (h_cur && entry_holds_fragments(e0)) { emit_fragments(fp, tc, e0); h_cur = false; }
         if (h_cur) h_cur = load_raster_tri(fp, e0, t_cur);
         h_mid = i1 < n && fetch(i1, e_mid);
     }
@@ -1278,6 +1383,7 @@ __device__ __forceinline__ void raster_stream(const FrameParams& fp, const TileC
         const uint32_t i2 = entry_of(base + 2u * TILE_THREADS);
         h_in = i2 < n && fetch(i2, e_in);
         h_next = h_mid;
+        if (h_next && entry_holds_fragments(e_mid)) { emit_fragments(fp, tc, e_mid); h_next = false; }
         if (h_next) h_next = load_raster_tri(fp, e_mid, t_next);
         raster_batch<S>(fp, tc, h_cur, t_cur);
         t_cur = t_next; h_cur = h_next;
