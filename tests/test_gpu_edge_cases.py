@@ -390,6 +390,57 @@ def test_tile_shards_compose_the_frame(device, oracle, shards):
     assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
 
 
+@pytest.mark.parametrize("case", [
+    dict(n=9000, extent=0.012),                                   # one or two pixels each: nearly all of them fragment entries
+    dict(n=9000, extent=0.03, depth_levels=3),                    # up to a dozen pixels: second entries and ordinary ones mixed, exact depth ties
+    dict(n=6000, extent=0.02, depth_levels=2, compare=1),         # LESS: the first of equal depths wins
+    dict(n=6000, extent=0.02, depth_test=False),                  # no depth test: the last submitted wins everywhere
+    dict(n=6000, extent=0.02, n_draws=5, z_range=(-0.2, 1.2)),    # several draws (primitive records), some clipped
+    dict(n=6000, extent=0.02, scissor=(37, 21, 90, 70)),          # boxes cut by the scissor
+    dict(n=4000, extent=0.015, mix=400),                          # a few large triangles among the small ones in every wave
+    dict(n=6000, extent=0.02, shader=scenes.SHADER_TEST_KTX),     # textured: shading of fragment-entry pixels
+])
+def test_meshes_of_tiny_triangles(device, oracle, case):
+    """Triangles of a few pixels are rasterised by setup and travel as fragments in the tile lists: coverage,
+    depth, ties and shading must come out as if the tile kernel had walked them, across tile borders too."""
+    shader = case.get("shader", scenes.SHADER_PUSH_CONSTANTS)
+    kw = dict(depth_compare=case.get("compare", 3), cull_mode=0)
+    if not case.get("depth_test", True):
+        kw.update(depth_test=False, depth_write=False)
+    sc = helpers.soup_scene(200, 136, case["n"], 41, max_extent=case["extent"], depth_levels=case.get("depth_levels", 0),
+                            z_range=case.get("z_range", (0.05, 0.95)), n_draws=case.get("n_draws", 1), shader=shader,
+                            texture=tex(64, 2) if shader == scenes.SHADER_TEST_KTX else None, pipeline_kw=kw)
+    if "mix" in case:  # every tenth triangle of the first `mix` blown up
+        v = sc.vbs[0].reshape(-1, 3, 8)
+        for t in range(0, case["mix"], 10):
+            c = v[t, :, :3].mean(axis=0)
+            v[t, :, :2] = c[:2] + (v[t, :, :2] - c[:2]) * 25.0
+    if "scissor" in case:
+        sc.scissor = case["scissor"]
+    check(sc, device, oracle)
+
+
+def test_tiny_triangles_under_tile_shards(device):
+    """Fragment entries are binned like any other: sharded by tiles, the shards still compose the frame."""
+    sc = helpers.soup_scene(200, 136, 8000, 43, max_extent=0.02, depth_levels=2, pipeline_kw=dict(cull_mode=0))
+    full_c, full_d = gpu_render(sc, device)
+    acc_c, acc_d = np.zeros_like(full_c), np.zeros_like(full_d)
+    tiles_x = (sc.width + 31) // 32
+    for k in range(3):
+        r = SceneRunner(sc, device)
+        try:
+            r.cmd.set_tile_shard(k, 3)
+            c, d = r.render()
+        finally:
+            r.destroy()
+        for ty in range((sc.height + 31) // 32):
+            for tx in range(tiles_x):
+                if (ty * tiles_x + tx) % 3 == k:
+                    sl = (slice(ty * 32, ty * 32 + 32), slice(tx * 32, tx * 32 + 32))
+                    acc_c[sl], acc_d[sl] = c[sl], d[sl]
+    assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
+
+
 @pytest.mark.parametrize("bands", [2, 3, 8])
 @pytest.mark.parametrize("samples", [1, 4])
 def test_bands_compose_the_frame(device, oracle, bands, samples):
