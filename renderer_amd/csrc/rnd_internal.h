@@ -51,20 +51,11 @@ struct __attribute__((aligned(16))) ShadeTables {
 constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   /* primitive slot (submission number) */
 constexpr uint32_t ENTRY_SUB_SHIFT = 28;      /* bits 28..30: fan index of a clipped primitive's triangle */
 constexpr uint32_t FLAG_CLIPPED = 0x80000000u;
-constexpr int FRAG_BOX_W = 8, FRAG_BOX_H = 4, FRAG_BOX_PIXELS = 16, FRAG_MAX = 3;
 constexpr uint32_t MAX_FAN = 7;               /* a triangle clipped by 6 planes has at most 9 corners */
 
 /* One triangle in a tile's list: 16 bytes, read with one dwordx4 per lane.
  * Unclipped: a,b,c index svtx[] and are ordered so the area is positive.
- * Clipped (FLAG_CLIPPED): a indexes clip_tris[].
- * Fragments (FLAG_CLIPPED clear, bits 28..30 = n in 1..FRAG_MAX): setup has already rasterised the triangle,
- * whose box is at most FRAG_BOX_W x FRAG_BOX_H and FRAG_BOX_PIXELS pixels; the entry holds n covered pixels, in row order, and their
- * depths.  With (x, y) the first of them and (ox_k, oy_k) = the k-th pixel's offset from it (ox in -8..7, oy in 0..3):
- *   a = D24 of fragment 0 | (x & 63) << 24 | (y & 3) << 30
- *   b = D24 of fragment 1 | oy_1 << 24 | (ox_2 + 8) << 26 | oy_2 << 30
- *   c = D24 of fragment 2 | ((y >> 2) & 15) << 24 | (ox_1 + 8) << 28
- * Positions are kept modulo 64, which is enough for a tile to find those of the box's pixels that are its own.
- * A triangle that covers up to 2 * FRAG_MAX pixels gets two such entries. */
+ * Clipped (FLAG_CLIPPED): a indexes clip_tris[]. */
 struct TileEntry {
     uint32_t a, b, c;
     uint32_t slot_flags;

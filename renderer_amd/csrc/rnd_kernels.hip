@@ -500,91 +500,9 @@ __device__ __forceinline__ void clip_primitive(const FrameParams& fp, const Draw
     }
 }
 
-/* Rasterises a triangle whose box [x0,x1] x [y0,y1] is at most FRAG_BOX_W x FRAG_BOX_H pixels, here in
- * setup, with the integers and the depth arithmetic of the tile kernel's walk (EdgeSetup): the edge
- * functions at the box's first pixel centre, stepped by a constant per pixel in row order, top-left rule
- * as a bias of one, depth from the unbiased values of edges 1 and 2.  Corners a, b, c in positive-area
- * order.  The covered pixels come back as up to two tile entries' worth of payload (FRAG_MAX fragments
- * each, layout at TileEntry); count is the number of covered pixels, which may exceed what was kept. */
-struct MicroFragments {
-    uint32_t count;
-    uint32_t a[2], b[2], c[2];
-};
-
-__device__ __forceinline__ MicroFragments micro_fragments(uint32_t depth_test, int32_t ax, int32_t ay, int32_t bx, int32_t by,
-                                                          int32_t cx, int32_t cy, float za, float zb, float zc, float inv_area,
-                                                          int x0, int y0, int x1, int y1)
-{
-    const int32_t dx0 = cx - bx, dy0 = cy - by;
-    const int32_t dx1 = ax - cx, dy1 = ay - cy;
-    const int32_t dx2 = bx - ax, dy2 = by - ay;
-    const int32_t bias0 = owns_edge(bx, by, cx, cy) ? 0 : 1;
-    const int32_t bias1 = owns_edge(cx, cy, ax, ay) ? 0 : 1;
-    const int32_t bias2 = owns_edge(ax, ay, bx, by) ? 0 : 1;
-    const int32_t px = x0 * 256 + 128, py = y0 * 256 + 128;
-    const int32_t r0 = __mul24(dx0, py - by) - __mul24(dy0, px - bx) - bias0;
-    const int32_t r1 = __mul24(dx1, py - cy) - __mul24(dy1, px - cx) - bias1;
-    const int32_t r2 = __mul24(dx2, py - ay) - __mul24(dy2, px - ax) - bias2;
-    const int32_t sx0 = -(dy0 << 8), sx1 = -(dy1 << 8), sx2 = -(dy2 << 8); /* one pixel right */
-    const int w = x1 - x0 + 1, n = w * (y1 - y0 + 1);
-    /* from the last pixel of a row to the first of the next: one down, w - 1 back */
-    const int32_t nl0 = (dx0 << 8) - (w - 1) * sx0, nl1 = (dx1 << 8) - (w - 1) * sx1, nl2 = (dx2 << 8) - (w - 1) * sx2;
-    /* first the coverage alone, one bit per pixel at row * FRAG_BOX_W + column */
-    uint32_t mask = 0;
-    {
-        int32_t e0 = r0, e1 = r1, e2 = r2;
-        uint32_t bit = 1u;
-        int col = 0;
-        for (int k = 0; k < n; ++k) {
-            if ((e0 | e1 | e2) >= 0) mask |= bit;
-            const bool last = ++col == w;
-            e0 += last ? nl0 : sx0; e1 += last ? nl1 : sx1; e2 += last ? nl2 : sx2;
-            bit <<= last ? (uint32_t)(FRAG_BOX_W - w + 1) : 1u;
-            if (last) col = 0;
-        }
-    }
-    MicroFragments mf;
-    mf.count = (uint32_t)__popc(mask);
-    mf.a[0] = mf.b[0] = mf.c[0] = mf.a[1] = mf.b[1] = mf.c[1] = 0;
-    if (mf.count > 2u * FRAG_MAX) return mf;
-    /* then the covered pixels one by one: depth, position, a place in an entry */
-    const float z0 = za, dz1 = zb - za, dz2 = zc - za;
-    const int32_t sy1 = dx1 << 8, sy2 = dx2 << 8;
-    int fx = 0, fy = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * FRAG_MAX; ++k) {
-        if (!mask) break;
-        const int bit = __ffs((int)mask) - 1;
-        mask &= mask - 1u;
-        const int col = bit & (FRAG_BOX_W - 1), row = bit / FRAG_BOX_W;
-        const int32_t e1 = r1 + bias1 + col * sx1 + row * sy1, e2 = r2 + bias2 + col * sx2 + row * sy2;
-        const float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
-        const float z = fma32(b2, dz2, fma32(b1, dz1, z0));
-        const uint32_t d = depth_test ? depth24(z) : 0u;
-        const int which = k / FRAG_MAX, at = k % FRAG_MAX;
-        if (at == 0) {
-            fx = col; fy = row;
-            const uint32_t x = (uint32_t)(x0 + col), y = (uint32_t)(y0 + row);
-            mf.a[which] = d | ((x & 63u) << 24) | ((y & 3u) << 30);
-            mf.c[which] |= ((y >> 2) & 15u) << 24;
-        } else {
-            const uint32_t ox = (uint32_t)(col - fx + 8), oy = (uint32_t)(row - fy);
-            if (at == 1) { mf.b[which] |= d | (oy << 24); mf.c[which] |= ox << 28; }
-            else { mf.c[which] |= d; mf.b[which] |= (ox << 26) | (oy << 30); }
-        }
-    }
-    return mf;
-}
-
 /* One wave per chunk of 64 primitives of one draw: fetch, classify, cull and orient, bin; then
  * clip the few that need it. */
-#ifndef SETUP_WAVES
-#define SETUP_WAVES 8
-#endif
-#ifndef RND_FRAG_ENTRIES
-#define RND_FRAG_ENTRIES 1
-#endif
-__global__ __launch_bounds__(256, SETUP_WAVES) void k_setup(FrameParams fp)
+__global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
 {
     __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -596,8 +514,7 @@ __global__ __launch_bounds__(256, SETUP_WAVES) void k_setup(FrameParams fp)
     const uint32_t tri = c.first + lane;
     const uint32_t slot = chunk * 64u + lane;
     bool valid = false, needs_clip = false;
-    TileEntry e = {0, 0, 0, slot}, e2 = {0, 0, 0, slot};
-    bool more = false;
+    TileEntry e = {0, 0, 0, slot};
     uint32_t box = BBOX_CULLED;
     PrimFetch pf;
     pf.idx[0] = pf.idx[1] = pf.idx[2] = 0;
@@ -618,43 +535,13 @@ __global__ __launch_bounds__(256, SETUP_WAVES) void k_setup(FrameParams fp)
                 PrimRec pr = {v0, v1, v2, c.draw};
                 if (!fp.direct_index) fp.prim_rec[slot] = pr;
                 /* what rasterisation needs: corners ordered for positive area */
-                /* orienting swaps corners 1 and 2 or nothing (selects, not an indexed read of pf.idx, which
-                 * would put the whole fetch record in private memory) */
-                const bool swapped = t.corner[1] == 2;
-                e.a = d.svtx_base + pf.idx[0];
-                e.b = d.svtx_base + (swapped ? pf.idx[2] : pf.idx[1]);
-                e.c = d.svtx_base + (swapped ? pf.idx[1] : pf.idx[2]);
-                /* A triangle of a few pixels is rasterised here and now, with its corners in registers: its
-                 * entry then carries fragments, and the tile kernel neither gathers its vertices nor walks
-                 * its box.  One that covers no pixel centre gets no entry at all. */
-                const int ext = max(max(t.x[0], max(t.x[1], t.x[2])) - min(t.x[0], min(t.x[1], t.x[2])),
-                                    max(t.y[0], max(t.y[1], t.y[2])) - min(t.y[0], min(t.y[1], t.y[2])));
-                const bool tiny = RND_FRAG_ENTRIES && fp.samples == 1 && x1 - x0 < FRAG_BOX_W && y1 - y0 < FRAG_BOX_H &&
-                                  (x1 - x0 + 1) * (y1 - y0 + 1) <= FRAG_BOX_PIXELS && ext < (1 << 14) && !RND_PROBE(fp, 32u);
-                /* Only when most of the wave's surviving triangles are that small (the lanes here are exactly
-                 * those): a tile batch that still holds several ordinary triangles pays for their gather and
-                 * walk whatever the other lanes carry, and then the work done here would be on top of it. */
-                const bool wave_is_tiny = 4 * __popcll(__ballot(tiny)) >= 3 * __popcll(__ballot(true));
-                if (tiny && wave_is_tiny) {
-                    const MicroFragments mf = micro_fragments(fp.depth_test, t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2],
-                                                              t.z[0], t.z[1], t.z[2], t.inv_area, x0, y0, x1, y1);
-                    if (mf.count == 0) {
-                        valid = false;
-                    } else if (mf.count <= 2u * FRAG_MAX) {
-                        e.a = mf.a[0]; e.b = mf.b[0]; e.c = mf.c[0];
-                        e.slot_flags = slot | (min(mf.count, (uint32_t)FRAG_MAX) << ENTRY_SUB_SHIFT);
-                        if (mf.count > (uint32_t)FRAG_MAX) {
-                            more = true;
-                            e2.a = mf.a[1]; e2.b = mf.b[1]; e2.c = mf.c[1];
-                            e2.slot_flags = slot | ((mf.count - FRAG_MAX) << ENTRY_SUB_SHIFT);
-                        }
-                    }
-                }
+                e.a = d.svtx_base + pf.idx[t.corner[0]];
+                e.b = d.svtx_base + pf.idx[t.corner[1]];
+                e.c = d.svtx_base + pf.idx[t.corner[2]];
             }
         }
     }
     if (!RND_PROBE(fp, 8u)) bin_wave(fp, valid, e, box);
-    if (__ballot(more)) bin_wave(fp, more, e2, box); /* the second entry of triangles with more than FRAG_MAX fragments */
 
     /* Primitives that cross the near plane, the far plane or the guard band (rare): the wave clips
      * them CLIP_LANES at a time, lane j taking the j-th of them, with the polygons in LDS. */
@@ -855,31 +742,6 @@ __device__ __forceinline__ void raster_wave(const FrameParams& fp, const TileCtx
         const int x = bx + lx, y = by + ly;
         if (x <= x1 && y <= y1) es.pixel(tc, x, y);
     }
-}
-
-/* An entry whose triangle setup has already rasterised: its fragments go straight to the tile's words.
- * Positions are modulo 64; a pixel is this tile's when its offset from the tile's first pixel, modulo 64, is
- * below 32 in both directions (the box is a few pixels, so no other pixel of it can alias). */
-__device__ __forceinline__ bool entry_holds_fragments(const TileEntry& e)
-{
-    return (e.slot_flags & (FLAG_CLIPPED | (7u << ENTRY_SUB_SHIFT))) - 1u < (FLAG_CLIPPED - 1u); /* sub != 0 and not clipped */
-}
-
-__device__ __forceinline__ void emit_fragments(const FrameParams& fp, const TileCtx& tc, const TileEntry& e)
-{
-    const uint32_t slot = e.slot_flags & SLOT_MASK, n = (e.slot_flags >> ENTRY_SUB_SHIFT) & 7u;
-    const uint32_t ord = fp.depth_less ? slot : ~slot;
-    const unsigned long long payload = (unsigned long long)ord << 8;
-    const uint32_t x = (((e.a >> 24) & 63u) - (uint32_t)tc.px0) & 63u;
-    const uint32_t y = (((e.a >> 30) | (((e.c >> 24) & 15u) << 2)) - (uint32_t)tc.py0) & 63u;
-    const uint32_t x1 = (x + (e.c >> 28) - 8u) & 63u, y1 = (y + ((e.b >> 24) & 3u)) & 63u;
-    const uint32_t x2 = (x + ((e.b >> 26) & 15u) - 8u) & 63u, y2 = (y + (e.b >> 30)) & 63u;
-    if (x < (uint32_t)TILE_W && y < (uint32_t)TILE_H)
-        atomicMin(&tc.keys[y * TILE_W + x], ((unsigned long long)(e.a & 0xFFFFFFu) << 40) | payload);
-    if (n > 1u && x1 < (uint32_t)TILE_W && y1 < (uint32_t)TILE_H)
-        atomicMin(&tc.keys[y1 * TILE_W + x1], ((unsigned long long)(e.b & 0xFFFFFFu) << 40) | payload);
-    if (n > 2u && x2 < (uint32_t)TILE_W && y2 < (uint32_t)TILE_H)
-        atomicMin(&tc.keys[y2 * TILE_W + x2], ((unsigned long long)(e.c & 0xFFFFFFu) << 40) | payload);
 }
 
 /* entry -> triangle; false when the entry must not be drawn */
@@ -1409,7 +1271,6 @@ __device__ __forceinline__ void raster_stream(const FrameParams& fp, const TileC
         TileEntry e0;
         const uint32_t i0 = entry_of(0), i1 = entry_of(TILE_THREADS);
         h_cur = i0 < n && fetch(i0, e0);
-        if (h_cur && entry_holds_fragments(e0)) { emit_fragments(fp, tc, e0); h_cur = false; }
         if (h_cur) h_cur = load_raster_tri(fp, e0, t_cur);
         h_mid = i1 < n && fetch(i1, e_mid);
     }
@@ -1417,7 +1278,6 @@ __device__ __forceinline__ void raster_stream(const FrameParams& fp, const TileC
         const uint32_t i2 = entry_of(base + 2u * TILE_THREADS);
         h_in = i2 < n && fetch(i2, e_in);
         h_next = h_mid;
-        if (h_next && entry_holds_fragments(e_mid)) { emit_fragments(fp, tc, e_mid); h_next = false; }
         if (h_next) h_next = load_raster_tri(fp, e_mid, t_next);
         raster_batch<S>(fp, tc, h_cur, t_cur);
         t_cur = t_next; h_cur = h_next;
