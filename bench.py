@@ -33,6 +33,7 @@ from renderer_amd import api, hostmath as hm, scenes  # noqa: E402
 from renderer_amd.runner import SceneRunner  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+VALU_CYCLES = 2.4      # cycles a SIMD spends per wave-wide vector instruction when it has waves to choose from
 
 
 def build_scene(cfg):
@@ -325,9 +326,11 @@ def main():
                     "algorithmic_bytes_per_launch": share,
                     "kernel_ms": round(stages[dom], 5)}
         if valu:
-            # what the kernel is actually short of: a wave's vector instruction occupies its SIMD
-            # for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
-            roofline["valu_busy"] = round(valu * 4.0 / (1024 * stages[dom] * 1e-3 * 2.4e9), 4)
+            # Vector-ALU occupation, for the record beside the HBM fraction: a SIMD with two or more waves to
+            # choose from issues one wave-wide vector instruction per VALU_CYCLES cycles (measured,
+            # tools/micro/valu_rate.hip: 2.1 for v_fma_f32, 2.4-2.6 for 32-bit integer adds; a wave on its own
+            # gets one per 4.5); 256 CUs x 4 SIMDs at 2.4 GHz
+            roofline["valu_busy"] = round(valu * VALU_CYCLES / (1024 * stages[dom] * 1e-3 * 2.4e9), 4)
 
     cpu = None
     if rank == 0 and not args.no_cpu:
