@@ -69,6 +69,7 @@ struct rnd_device_t {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    uint64_t geometry_epoch = 0;   /* counts writes into vertex buffers: boxes computed before the last one are stale */
     ShadeTables* tables = nullptr; /* sRGB decode/encode tables in device memory */
     ShadeTables host_tables;       /* the same tables on the host */
     /* pinned ring for small host->device writes (the per-frame uniform block): the copy is
@@ -194,6 +195,7 @@ struct rnd_cmd_t {
     DeviceArray<uint32_t> d_tile_count, d_counters;
     FrameParams fp = {};
     uint32_t shard_index = 0, shard_count = 1;
+    uint64_t geometry_epoch = 0;   /* the device's when the draws' boxes were computed */
 
     void release_compiled()
     {
@@ -504,6 +506,7 @@ int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t 
         return RND_SUCCESS;
     }
     if (int r = flush_pending(dev)) return r;
+    if (buf->usage & RND_BUFFER_USAGE_VERTEX) ++dev->geometry_epoch;
     if (bytes <= rnd_device_t::STAGE_SLOT_BYTES) return staged_write(dev, buf->ptr + offset, src, (size_t)bytes);
     /* a large upload (geometry): frames in flight may still read the buffer, wait them out */
     HIP_TRY(sync_all(dev));
@@ -518,6 +521,7 @@ int rnd_buffer_write_device(rnd_buffer buf, uint64_t offset, const void* device_
     if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(RND_ERROR_INVALID_ARGUMENT, "buffer_write_device: range outside the buffer");
     if (int r = set_device(buf->dev)) return r;
     if (int r = flush_pending(buf->dev)) return r;
+    if (buf->usage & RND_BUFFER_USAGE_VERTEX) ++buf->dev->geometry_epoch;
     /* queued on the device's stream behind every frame already submitted; later frames follow it */
     HIP_TRY(follow_frames(buf->dev));
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, device_src, (size_t)bytes, hipMemcpyDeviceToDevice, buf->dev->stream));
@@ -1028,6 +1032,7 @@ int rnd_cmd_end(rnd_cmd cmd)
 
     /* The box of every draw's vertices, for culling whole draws when the work executes.  A pass of one
      * draw gets none (that draw is the pass).  Draws over the same vertices share one job. */
+    cmd->geometry_epoch = dev->geometry_epoch;
     if (n >= 2) {
         std::vector<BoundsJob> bjobs;
         std::vector<uint32_t> bjob_of(n, 0xFFFFFFFFu);
@@ -1244,6 +1249,8 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     if (int r = set_device(dev)) return r;
     FrameParams fp = cmd->fp;
     fp.shard_index = cmd->shard_index; fp.shard_count = cmd->shard_count;
+    /* vertex data written since recording: the boxes no longer bound it, draw everything */
+    fp.cull_draws = cmd->geometry_epoch == dev->geometry_epoch ? 1u : 0u;
 #ifdef RND_PROBES
     { const char* dbg = getenv("RND_DEBUG"); fp.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u; }
 #else

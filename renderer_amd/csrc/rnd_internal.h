@@ -208,6 +208,7 @@ struct FrameParams {
      * box of vertices lies wholly beyond one of these four planes, the near plane or the far plane has no
      * fragment inside the rectangle (a device that renders one band of a frame skips the other bands' draws) */
     float cull_lo_x, cull_hi_x, cull_lo_y, cull_hi_y;
+    uint32_t cull_draws;     /* 0: the boxes are stale (vertex data was written after recording), nothing is culled */
     int32_t clamp_x0, clamp_y0, clamp_x1, clamp_y1; /* inclusive pixel rectangle fragments may land in */
     int32_t area_x0, area_y0, area_x1, area_y1;     /* inclusive render area (cleared and stored) */
     float half_w, half_h, ox, oy, pz, zmin;

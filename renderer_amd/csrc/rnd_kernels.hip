@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     const Chunk c = fp.vchunks[chunk];
     const DrawStatic& d = fp.draws[c.draw];
     float m[16], nm[9], mine;
-    const bool cullable = d.has_bounds != 0u;
+    const bool cullable = d.has_bounds != 0u && fp.cull_draws != 0u;
     if (cullable) {
         /* a draw with a box is tested before anything of it is fetched: a culled one costs its waves
          * the matrices and nothing else, and setup skips its primitives */

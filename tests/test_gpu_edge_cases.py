@@ -502,6 +502,28 @@ def test_draws_outside_the_frustum_are_skipped(device, oracle):
     assert visible == n_inside + len(kept)
 
 
+def test_vertex_data_written_after_recording_is_drawn(device, oracle):
+    """The boxes used for culling are computed when the command buffer is recorded; vertex data written
+    afterwards (here: the mesh moved from far off-screen into view) must still be drawn."""
+    sc = scenes.instanced_spheres(192, 128, 3, 2, 1, 7, tex_size=32)
+    inside = sc.vbs[0].copy()
+    far = inside.copy().reshape(-1, 8)
+    far[:, 0] += 500.0  # every draw's box is now beyond the right plane
+    sc.vbs[0] = far.reshape(inside.shape)
+    r = SceneRunner(sc, device)
+    try:
+        r.render()
+        assert r.cmd.visible_draws() == 0
+        r.vbs[0].write(inside)  # same command buffer, new vertex data
+        color, depth = r.render()
+        assert r.cmd.visible_draws() == len(sc.draws)
+    finally:
+        r.destroy()
+    sc.vbs[0] = inside
+    oc, od, _ = oracle.render_scene(sc, threads=8)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
 def test_scissored_pass_skips_draws_and_tiles_outside(device, oracle):
     """A scissor inside the render area inside the target, none aligned to tiles: draws outside the scissor
     are skipped, pixels inside the area but outside the scissor are cleared, pixels outside the area are
