@@ -293,6 +293,8 @@ def main():
         if tiles_check != "exact":
             raise SystemExit("tile-sharded frame differs from the unsharded frame: " + tiles_check)
     frames_total = args.steps * (1 if tiles_mode else world)
+    if args.one_shard_of > 1 and not tiles_mode:
+        frames_total /= args.one_shard_of  # a rehearsal renders one rank's share of every frame
     pixels = scene.width * scene.height
     mpix = pixels * frames_total / elapsed / 1e6
     mtri = scene.triangle_count() * frames_total / elapsed / 1e6
