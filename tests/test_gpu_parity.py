@@ -86,6 +86,30 @@ def test_config3_full_and_tile_shards(device, oracle):
         assert np.array_equal(c[mine], color[mine]) and np.array_equal(d[mine], depth[mine])
 
 
+def test_config3_full_bands(device):
+    """The other way configs[3] is divided over GPUs, at full size: each of 8 ranks renders a band of whole rows
+    of tiles as its render area and skips the draws outside it.  Every band's rows equal the unsharded frame's
+    (checked against the oracle by the test above), and no rank keeps more than a quarter of the draws."""
+    from renderer_amd import sharding
+    sc = scenes.config3()
+    r = SceneRunner(sc, device)
+    try:
+        color, depth = r.render()
+    finally:
+        r.destroy()
+    kept = []
+    for k in range(8):
+        y0, y1 = sharding.band_rows(sc.height, k, 8)
+        r = SceneRunner(sharding.band_scene(sc, k, 8), device)
+        try:
+            c, d = r.render()
+            kept.append(r.cmd.visible_draws())
+        finally:
+            r.destroy()
+        assert np.array_equal(c[y0:y1], color[y0:y1]) and np.array_equal(d[y0:y1], depth[y0:y1]), "band %d differs" % k
+    assert sum(kept) >= len(sc.draws) and max(kept) <= len(sc.draws) // 4
+
+
 def test_config4_view_full(device, oracle):
     """One view of BASELINE configs[4] at full size: 1920x1080 over a 2237x2237-quad grid
     (10 008 338 triangles, most of them smaller than a pixel)."""
