@@ -1308,19 +1308,42 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
     for (int s = 0; s < S; ++s) untouched = untouched && vis[s] == VIS_NONE;
     if (untouched) { reinterpret_cast<uint32_t*>(fp.color)[pi] = fp.clear_packed; return; }
     float smp[S][4];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        int reuse = -1;
-#pragma unroll
-        for (int s2 = 0; s2 < s; ++s2) if (reuse < 0 && vis[s2] == vis[s]) reuse = s2;
-        if (reuse >= 0) {
-            smp[s][0] = smp[reuse][0]; smp[s][1] = smp[reuse][1]; smp[s][2] = smp[reuse][2]; smp[s][3] = smp[reuse][3];
-        } else if (vis[s] == VIS_NONE) {
-            smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
-        } else if (RND_PROBE(fp, 1u)) {
-            smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.5f;
+    if constexpr (S == 1) {
+        if (RND_PROBE(fp, 1u)) {
+            smp[0][0] = smp[0][1] = smp[0][2] = smp[0][3] = 0.5f;
         } else {
-            shade_pixel(fp, tb, pass_levels, vis[s] & SLOT_MASK, (vis[s] >> ENTRY_SUB_SHIFT) & 7u, (vis[s] & FLAG_CLIPPED) != 0u, x, y, smp[s]);
+            shade_pixel(fp, tb, pass_levels, vis[0] & SLOT_MASK, (vis[0] >> ENTRY_SUB_SHIFT) & 7u, (vis[0] & FLAG_CLIPPED) != 0u, x, y, smp[0]);
+        }
+    } else {
+        /* Several samples: one shading per distinct owner, as a loop with ONE copy of the shading code.  Each
+         * turn takes the first sample not yet coloured, shades its owner and colours every sample that owner
+         * holds; a wave runs as many turns as its pixel with the most owners needs (unrolled per sample, the
+         * code is four times the size and a wave runs a copy for every sample index at which any of its
+         * pixels meets a new owner). */
+        uint32_t todo = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (vis[s] == VIS_NONE) {
+                smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
+            } else {
+                smp[s][0] = smp[s][1] = smp[s][2] = smp[s][3] = 0.0f;
+                todo |= 1u << s;
+            }
+        }
+#pragma unroll 1
+        while (todo) {
+            uint32_t owner = 0;
+#pragma unroll
+            for (int s = S - 1; s >= 0; --s) if (todo & (1u << s)) owner = vis[s]; /* the first sample still to do */
+            float c[4];
+            shade_pixel(fp, tb, pass_levels, owner & SLOT_MASK, (owner >> ENTRY_SUB_SHIFT) & 7u, (owner & FLAG_CLIPPED) != 0u, x, y, c);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if ((todo & (1u << s)) && vis[s] == owner) {
+                    smp[s][0] = c[0]; smp[s][1] = c[1]; smp[s][2] = c[2]; smp[s][3] = c[3];
+                    todo &= ~(1u << s);
+                }
+            }
         }
     }
     float acc[4];
