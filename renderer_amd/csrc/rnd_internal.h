@@ -124,12 +124,14 @@ struct DrawStatic {
     uint32_t pad1[2];
 };
 
-/* Per-draw matrix derived from the uniform buffer each time the work executes: object space to
- * clip space.  The vertex kernel builds it per wave and stores it here for the clipper. */
+/* Per draw, derived from the uniform buffer each time the work executes: object space to clip space (for the
+ * clipper, and for the vertex kernel when a kernel of its own prepared it), the normal matrix, and whether
+ * the draw is drawn at all this frame. */
 struct DrawDerived {
     float clip_m[16];
+    float nrm_m[9];   /* written only by the per-draw kernel (passes of many draws) */
     uint32_t visible; /* 0: the draw's box misses the frustum or the rectangle this device renders; setup skips it */
-    uint32_t pad[3];
+    uint32_t pad[6];
 };
 
 /* Record-time job: the box of `count` positions read at vb + i * stride + off_pos.  The result is six
@@ -229,7 +231,7 @@ struct FrameParams {
 /* launch wrappers (rnd_kernels.hip) */
 void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n_jobs, hipStream_t s);
 void launch_bounds(const BoundsJob* jobs, uint32_t* out_min_max, uint32_t n_jobs, hipStream_t s);
-void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s);
+void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s); /* with the per-draw kernel first when the pass has many draws */
 void launch_setup(const FrameParams& fp, hipStream_t s);
 void launch_tile(const FrameParams& fp, hipStream_t s);
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,

@@ -283,7 +283,34 @@ __device__ __forceinline__ bool draw_is_outside(const FrameParams& fp, const Dra
     return outside;
 }
 
-/* One wave per chunk of 64 vertices of one draw. */
+/* A pass of many small draws: one wave per DRAW builds what the draw's vertex waves would each build again
+ * (a draw of 162 vertices has three of them, and the matrices are most of such a wave's instructions) -- the
+ * two matrices and the verdict on the draw's box.  The vertex kernel then starts from three scalar loads, and
+ * a culled draw costs each of its waves one of them. */
+constexpr uint32_t PER_DRAW_KERNEL_MIN_DRAWS = 256;
+
+__global__ __launch_bounds__(256) void k_draws(VertexArgs args)
+{
+    const FrameParams& fp = args.fp;
+    const uint32_t draw = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (draw >= fp.n_draws) return;
+    const DrawStatic& d = fp.draws[draw];
+    float m[16], nm[9];
+    const float mine = wave_matrix_element(args.up, d);
+    wave_clip_matrix(mine, m);
+    bool outside = d.vert_count == 0u;
+    if (d.has_bounds != 0u && fp.cull_draws != 0u) outside = outside || draw_is_outside(fp, d, m);
+    DrawDerived& out = fp.derived[draw];
+    if (lane_id() == 0) out.visible = outside ? 0u : 1u;
+    if (outside) return;
+    wave_normal_matrix(d, mine, nm);
+    if (lane_id() < 16u) out.clip_m[lane_id()] = mine;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) if (lane_id() == (uint32_t)i) out.nrm_m[i] = nm[i];
+}
+
+/* One wave per chunk of 64 vertices of one draw.  PREPARED: k_draws has run. */
+template <bool PREPARED>
 __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 {
     const FrameParams& fp = args.fp;
@@ -294,8 +321,11 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     if (chunk >= fp.n_vchunks) return;
     const Chunk c = fp.vchunks[chunk];
     const DrawStatic& d = fp.draws[c.draw];
-    float m[16], nm[9], mine;
-    const bool cullable = d.has_bounds != 0u && fp.cull_draws != 0u;
+    float m[16], nm[9], mine = 0.0f;
+    if constexpr (PREPARED) {
+        if (!fp.derived[c.draw].visible) return;
+    }
+    const bool cullable = !PREPARED && d.has_bounds != 0u && fp.cull_draws != 0u;
     if (cullable) {
         /* a draw with a box is tested before anything of it is fetched: a culled one costs its waves
          * the matrices and nothing else, and setup skips its primitives */
@@ -323,13 +353,22 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
             nrm[0] = load_f32(q); nrm[1] = load_f32(q + 1); nrm[2] = load_f32(q + 2);
         }
     }
-    if (!cullable) {
-        mine = wave_matrix_element(up, d);
-        wave_clip_matrix(mine, m);
-        if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = 1u;
+    if constexpr (PREPARED) {
+        /* wave-uniform addresses: scalar loads */
+        const DrawDerived& dd = fp.derived[c.draw];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = dd.clip_m[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) nm[i] = dd.nrm_m[i];
+    } else {
+        if (!cullable) {
+            mine = wave_matrix_element(up, d);
+            wave_clip_matrix(mine, m);
+            if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = 1u;
+        }
+        wave_normal_matrix(d, mine, nm);
+        if (c.first == 0 && lane_id() < 16u) fp.derived[c.draw].clip_m[lane_id()] = mine;
     }
-    wave_normal_matrix(d, mine, nm);
-    if (c.first == 0 && lane_id() < 16u) fp.derived[c.draw].clip_m[lane_id()] = mine;
     if (!live) return;
     /* vertex shader position: M * vec4(pos,1), then the reference's clip-space y = 1 - y
      * (test_ktx.vert:28-29, push_constants.vert:28-29, dummy.vert.glsl:22-23) */
@@ -1503,7 +1542,12 @@ void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t
     if (!blocks) return;
     VertexArgs args;
     args.fp = fp; args.up = patch;
-    hipLaunchKernelGGL(k_vertex, dim3(blocks), dim3(256), 0, s, args);
+    if (fp.n_draws >= PER_DRAW_KERNEL_MIN_DRAWS) {
+        hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + 3) / 4), dim3(256), 0, s, args);
+        hipLaunchKernelGGL(k_vertex<true>, dim3(blocks), dim3(256), 0, s, args);
+    } else {
+        hipLaunchKernelGGL(k_vertex<false>, dim3(blocks), dim3(256), 0, s, args);
+    }
 }
 
 void launch_setup(const FrameParams& fp, hipStream_t s)

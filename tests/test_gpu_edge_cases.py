@@ -524,11 +524,12 @@ def test_vertex_data_written_after_recording_is_drawn(device, oracle):
     assert np.array_equal(depth, od) and np.array_equal(color, oc)
 
 
-def test_scissored_pass_skips_draws_and_tiles_outside(device, oracle):
+@pytest.mark.parametrize("grid", [(8, 6), (16, 10)])
+def test_scissored_pass_skips_draws_and_tiles_outside(device, oracle, grid):
     """A scissor inside the render area inside the target, none aligned to tiles: draws outside the scissor
     are skipped, pixels inside the area but outside the scissor are cleared, pixels outside the area are
-    left alone."""
-    sc = scenes.instanced_spheres(320, 224, 8, 6, 2, 3, tex_size=32)
+    left alone.  96 draws (every vertex wave tests its draw) and 320 (a kernel of its own tests each draw once)."""
+    sc = scenes.instanced_spheres(320, 224, grid[0], grid[1], 2, 3, tex_size=32)
     sc.area = (37, 41, 230, 150)
     sc.scissor = (70, 60, 100, 75)
     r = SceneRunner(sc, device)
