@@ -335,7 +335,7 @@ def main():
             roofline["valu_busy"] = round(valu * VALU_CYCLES / (1024 * stages[dom] * 1e-3 * 2.4e9), 4)
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:  # the CPU leg belongs to the single-GPU line only
         cpu = cpu_baseline(scene)
 
     if rank == 0:
