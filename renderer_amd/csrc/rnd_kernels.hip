@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_vchunks) return;
-    const Chunk c = fp.vchunks[chunk];
+    Chunk c = {0u, chunk * 64u}; /* what the chunk table of a one-draw pass holds */
+    if (!fp.direct_index) c = fp.vchunks[chunk];
     const DrawStatic& d = fp.draws[c.draw];
     float m[16], nm[9], mine = 0.0f;
     if constexpr (PREPARED) {
