@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on a GPU: triangle soups over the knobs together (target size, triangle count and
+extent from sub-pixel to screen-filling, depth range across both planes, exact depth ties, draw count, shader,
+texture and sampler, cull state, compare op, sample count, render area and scissor), each frame against the oracle.
+
+    python tools/fuzz_soup.py [CASES] [FIRST_SEED]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers  # noqa: E402
+from renderer_amd import api, scenes  # noqa: E402
+from renderer_amd.runner import SceneRunner  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def case(seed):
+    rng = np.random.RandomState(50000 + seed)
+    w, h = int(rng.randint(1, 420)), int(rng.randint(1, 300))
+    shader = [scenes.SHADER_PUSH_CONSTANTS, scenes.SHADER_TEST_KTX, scenes.SHADER_DUMMY][int(rng.randint(0, 3))]
+    texture = None
+    if shader != scenes.SHADER_PUSH_CONSTANTS:
+        texture = dict(texels=scenes.checker_texture(int(rng.choice([16, 24, 40, 128, 200])), seed), gen_mips=bool(rng.randint(0, 2)),
+                       filtering=int(rng.randint(0, 2)), tiled=bool(rng.randint(0, 2)), fmt=int(rng.choice([37, 43])))
+    kw = dict(cull_mode=int(rng.randint(0, 4)), front_face=int(rng.randint(0, 2)), depth_compare=int(rng.choice([1, 3])))
+    if rng.rand() < 0.1:
+        kw.update(depth_test=False, depth_write=False)
+    sc = helpers.soup_scene(w, h, int(rng.choice([1, 40, 700, 6000, 20000])), seed,
+                            max_extent=float(rng.choice([0.011, 0.02, 0.05, 0.3, 2.5])),
+                            depth_levels=int(rng.choice([0, 0, 1, 3])), z_range=[(0.05, 0.95), (-0.3, 1.3)][int(rng.randint(0, 2))],
+                            shader=shader, n_draws=int(rng.choice([1, 1, 2, 7, 30])), texture=texture,
+                            samples=int(rng.choice([1, 1, 4])), pipeline_kw=kw)
+    if rng.rand() < 0.3:
+        ax, ay = int(rng.randint(0, max(w // 2, 1))), int(rng.randint(0, max(h // 2, 1)))
+        sc.area = (ax, ay, int(rng.randint(1, w - ax + 1)), int(rng.randint(1, h - ay + 1)))
+    if rng.rand() < 0.3:
+        sx, sy = int(rng.randint(0, w)), int(rng.randint(0, h))
+        sc.scissor = (sx, sy, int(rng.randint(0, w - sx + 1)), int(rng.randint(0, h - sy + 1)))
+    return sc
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    dev = api.Device(0)
+    bad = 0
+    for seed in range(first, first + cases):
+        sc = case(seed)
+        r = SceneRunner(sc, dev)
+        try:
+            color, depth = r.render()
+        finally:
+            r.destroy()
+        oc, od, _ = oracle.render_scene(sc, threads=8)
+        ax, ay, aw, ah = sc.area
+        sl = (slice(ay, ay + ah), slice(ax, ax + aw))
+        if not (np.array_equal(depth[sl], od[sl]) and np.array_equal(color[sl], oc[sl])):
+            bad += 1
+            print("seed %d: MISMATCH depth %d colour %d (%dx%d s%d, %d tris in %d draws, area %s scissor %s)" % (
+                seed, int((depth[sl] != od[sl]).sum()), int((color[sl] != oc[sl]).sum()), sc.width, sc.height, sc.samples,
+                sc.triangle_count(), len(sc.draws), sc.area, sc.scissor), flush=True)
+        elif seed % 25 == 0:
+            print("seed %d ok" % seed, flush=True)
+    dev.destroy()
+    print("%d cases, %d mismatches" % (cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
