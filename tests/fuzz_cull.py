@@ -3,7 +3,7 @@
 instanced meshes under random cameras, random per-draw transforms (many partly or wholly outside the frustum,
 some crossing the near plane, some enclosing the camera), random render areas and scissors.
 
-    python tools/fuzz_cull.py [CASES] [FIRST_SEED]
+    python tests/fuzz_cull.py [CASES] [FIRST_SEED]
 """
 import os
 import sys

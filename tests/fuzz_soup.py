@@ -3,7 +3,7 @@
 extent from sub-pixel to screen-filling, depth range across both planes, exact depth ties, draw count, shader,
 texture and sampler, cull state, compare op, sample count, render area and scissor), each frame against the oracle.
 
-    python tools/fuzz_soup.py [CASES] [FIRST_SEED]
+    python tests/fuzz_soup.py [CASES] [FIRST_SEED]
 """
 import os
 import sys

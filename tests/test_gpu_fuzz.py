@@ -1,0 +1,39 @@
+"""A bounded run of the randomised parity sweeps fuzz_soup.py and fuzz_cull.py (the same generators, fewer cases): triangle
+soups over all the knobs together, and instanced meshes under random cameras, transforms, render areas and
+scissors (whole-draw culling)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_cull  # noqa: E402
+import fuzz_soup  # noqa: E402
+from renderer_amd.runner import SceneRunner  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def inside_area_equal(sc, device, oracle):
+    r = SceneRunner(sc, device)
+    try:
+        color, depth = r.render()
+    finally:
+        r.destroy()
+    oc, od, _ = oracle.render_scene(sc, threads=8)
+    ax, ay, aw, ah = sc.area
+    sl = (slice(ay, ay + ah), slice(ax, ax + aw))
+    return np.array_equal(depth[sl], od[sl]) and np.array_equal(color[sl], oc[sl])
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_soup_sweep(device, oracle, block):
+    bad = [s for s in range(1000 + 25 * block, 1025 + 25 * block) if not inside_area_equal(fuzz_soup.case(s), device, oracle)]
+    assert not bad, "seeds that differ from the oracle: %s" % bad
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_culling_sweep(device, oracle, block):
+    bad = [s for s in range(5000 + 40 * block, 5040 + 40 * block) if not inside_area_equal(fuzz_cull.case(s), device, oracle)]
+    assert not bad, "seeds that differ from the oracle: %s" % bad
