@@ -123,7 +123,11 @@ int rnd_device_stage_times(rnd_device dev, float* ms, int count);
 int rnd_buffer_create(rnd_device dev, uint64_t bytes, uint32_t usage, const void* init, rnd_buffer* out);
 /* vmaMapMemory / memcpy / vmaFlushAllocation / vmaUnmapMemory (base_obj_viewer_app.cpp:134-138).
  * Frames submitted before the call keep the old bytes, frames submitted after it see the new
- * ones.  Up to 512 bytes into a uniform buffer cost no copy at all. */
+ * ones.  Up to 512 bytes into a buffer whose only usage is UNIFORM cost no copy at all.
+ * Vertex data may be rewritten between submits (whole-draw culling is then off for command
+ * buffers recorded earlier).  Index data may not: how many vertices a draw transforms is scanned
+ * from its indices at rnd_cmd_end, so rnd_submit of a command buffer recorded before a write into
+ * an index buffer fails with RND_ERROR_RECORDING until it is recorded again. */
 int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t bytes);
 /* same, source already in device memory (device-to-device on the device's stream) */
 int rnd_buffer_write_device(rnd_buffer buf, uint64_t offset, const void* device_src, uint64_t bytes);
@@ -151,8 +155,11 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
 int rnd_target_read(rnd_target target, void* color_out, uint32_t* depth_out);
 void* rnd_target_color_device_ptr(rnd_target target); /* resolved colour image in device memory, row-major */
 /* no reference analogue: queue a device-to-device copy of the resolved colour image
- * (width*height*4 bytes) on the device's stream, e.g. into the send buffer of the
- * multi-GPU frame gather.  Does not wait. */
+ * (width*height*4 bytes), e.g. into the send buffer of the multi-GPU frame gather.  The copy
+ * runs behind the last frame rendered into the target, on that frame's stream (which is
+ * rnd_device_stream() only for a device created on a caller-supplied stream), and a later frame
+ * into the target follows it.  Does not wait: before another stream or the host reads
+ * device_dst, wait for a fence of a later submit, rnd_device_wait_idle or rnd_target_read. */
 int rnd_target_copy_color(rnd_target target, void* device_dst);
 /* the same for rows [first_row, first_row + row_count) only (row_count*width*4 bytes): what a device
  * that renders one band of the frame (its render area) contributes to the gather */

@@ -194,6 +194,7 @@ class Pipeline(_Handle):
                  depth_compare=COMPARE_LESS_OR_EQUAL, samples=1, topology=TOPOLOGY_TRIANGLE_LIST,
                  color_write_mask=0xF, blend_enable=False):
         super().__init__()
+        self.dev = dev  # children keep their device alive: it must be destroyed last
         self.info = PipelineInfo(
             shader,
             VertexAttribute(FORMAT_R32G32B32_SFLOAT, off_pos),
@@ -209,6 +210,7 @@ class Fence(_Handle):
 
     def __init__(self, dev):
         super().__init__()
+        self.dev = dev  # rnd_fence_destroy reads the device
         _check(_lib.load().rnd_fence_create(dev.h, C.byref(self.h)))
 
     def wait(self):

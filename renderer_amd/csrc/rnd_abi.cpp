@@ -96,7 +96,8 @@ struct rnd_device_t {
     std::vector<rnd_cmd> cmds;
     std::vector<rnd_target> targets;
     hipEvent_t order_ev = nullptr;
-    bool stream_dirty = false;
+    uint64_t upload_seq = 0;       /* counts the pieces of work queued on the device's own stream */
+    uint64_t index_epoch = 0;      /* counts writes into index buffers: vertex counts scanned before the last one are stale */
     bool profiling = false;
     hipEvent_t ev[RND_STAGE_COUNT + 1] = {};
     float stage_ms[RND_STAGE_COUNT] = {};
@@ -196,6 +197,8 @@ struct rnd_cmd_t {
     FrameParams fp = {};
     uint32_t shard_index = 0, shard_count = 1;
     uint64_t geometry_epoch = 0;   /* the device's when the draws' boxes were computed */
+    uint64_t index_epoch = 0;      /* the device's when the draws' index ranges were scanned */
+    uint64_t seen_seq = 0;         /* the device's upload_seq this command buffer's stream has been ordered behind */
 
     void release_compiled()
     {
@@ -222,8 +225,7 @@ hipError_t sync_all(rnd_device dev)
         const hipError_t e2 = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = e2;
     }
-    dev->stream_dirty = false;
-    for (rnd_cmd c : dev->cmds) c->submitted = false;
+    for (rnd_cmd c : dev->cmds) { c->submitted = false; c->seen_seq = dev->upload_seq; }
     return e;
 }
 
@@ -260,7 +262,7 @@ int staged_write(rnd_device dev, uint8_t* dst, const void* src, size_t bytes)
     HIP_TRY(hipMemcpyAsync(dst, staging, bytes, hipMemcpyHostToDevice, dev->stream));
     HIP_TRY(hipEventRecord(dev->stage_ev[slot], dev->stream));
     dev->stage_used[slot] = true;
-    dev->stream_dirty = true;
+    ++dev->upload_seq;
     return RND_SUCCESS;
 }
 
@@ -415,13 +417,22 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         rnd_device_destroy(dev);
         return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc tables failed");
     }
-    HIP_TRY(hipMemcpy(dev->tables, &host_tables, sizeof(ShadeTables), hipMemcpyHostToDevice));
-    for (int i = 0; i <= RND_STAGE_COUNT; ++i) HIP_TRY(hipEventCreate(&dev->ev[i]));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->stage_host), rnd_device_t::STAGE_SLOTS * rnd_device_t::STAGE_SLOT_BYTES, hipHostMallocDefault));
-    for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&dev->stage_ev[i], hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dev->status_host), 64, hipHostMallocDefault));
-    memset(dev->status_host, 0, 64);
-    HIP_TRY(hipEventCreateWithFlags(&dev->order_ev, hipEventDisableTiming));
+    /* a failure from here on releases what the device object already holds */
+    hipError_t e = hipMemcpy(dev->tables, &host_tables, sizeof(ShadeTables), hipMemcpyHostToDevice);
+    for (int i = 0; i <= RND_STAGE_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&dev->ev[i]);
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void**>(&dev->stage_host), rnd_device_t::STAGE_SLOTS * rnd_device_t::STAGE_SLOT_BYTES, hipHostMallocDefault);
+    for (int i = 0; i < rnd_device_t::STAGE_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&dev->stage_ev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&dev->status_host), 64, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        memset(dev->status_host, 0, 64);
+        e = hipEventCreateWithFlags(&dev->order_ev, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        rnd_device_destroy(dev);
+        return fail(e == hipErrorOutOfMemory ? RND_ERROR_OUT_OF_DEVICE_MEMORY : RND_ERROR_DEVICE_LOST,
+                    std::string("rnd_device_create: ") + hipGetErrorString(e));
+    }
     *out = dev;
     return RND_SUCCESS;
 }
@@ -494,7 +505,7 @@ int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t 
     if (int r = set_device(buf->dev)) return r;
     rnd_device dev = buf->dev;
     /* stream-ordered after earlier submits: a frame already queued still sees the old bytes */
-    if ((buf->usage & RND_BUFFER_USAGE_UNIFORM) && bytes <= PATCH_MAX_BYTES && bytes % 4 == 0 && offset % 4 == 0) {
+    if (buf->usage == RND_BUFFER_USAGE_UNIFORM && bytes <= PATCH_MAX_BYTES && bytes % 4 == 0 && offset % 4 == 0) {
         /* the per-frame uniform block (base_obj_viewer_app.cpp:134-138): no copy is queued; the
          * submits that follow take the bytes along in their kernel arguments */
         uint8_t* dst = buf->ptr + offset;
@@ -507,6 +518,7 @@ int rnd_buffer_write(rnd_buffer buf, uint64_t offset, const void* src, uint64_t 
     }
     if (int r = flush_pending(dev)) return r;
     if (buf->usage & RND_BUFFER_USAGE_VERTEX) ++dev->geometry_epoch;
+    if (buf->usage & RND_BUFFER_USAGE_INDEX) ++dev->index_epoch;
     if (bytes <= rnd_device_t::STAGE_SLOT_BYTES) return staged_write(dev, buf->ptr + offset, src, (size_t)bytes);
     /* a large upload (geometry): frames in flight may still read the buffer, wait them out */
     HIP_TRY(sync_all(dev));
@@ -522,10 +534,11 @@ int rnd_buffer_write_device(rnd_buffer buf, uint64_t offset, const void* device_
     if (int r = set_device(buf->dev)) return r;
     if (int r = flush_pending(buf->dev)) return r;
     if (buf->usage & RND_BUFFER_USAGE_VERTEX) ++buf->dev->geometry_epoch;
+    if (buf->usage & RND_BUFFER_USAGE_INDEX) ++buf->dev->index_epoch;
     /* queued on the device's stream behind every frame already submitted; later frames follow it */
     HIP_TRY(follow_frames(buf->dev));
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, device_src, (size_t)bytes, hipMemcpyDeviceToDevice, buf->dev->stream));
-    buf->dev->stream_dirty = true;
+    ++buf->dev->upload_seq;
     return RND_SUCCESS;
 }
 
@@ -682,7 +695,7 @@ int rnd_target_copy_color(rnd_target target, void* device_dst)
     hipStream_t s = target->last_valid ? target->last_stream : target->dev->stream;
     HIP_TRY(hipMemcpyAsync(device_dst, target->color, (size_t)target->width * target->height * 4, hipMemcpyDeviceToDevice, s));
     target->last_stream = s; target->last_valid = true;
-    if (s == target->dev->stream) target->dev->stream_dirty = true;
+    if (s == target->dev->stream) ++target->dev->upload_seq;
     return RND_SUCCESS;
 }
 
@@ -696,7 +709,7 @@ int rnd_target_copy_color_rows(rnd_target target, uint32_t first_row, uint32_t r
     const size_t pitch = (size_t)target->width * 4;
     HIP_TRY(hipMemcpyAsync(device_dst, target->color + (size_t)first_row * pitch, (size_t)row_count * pitch, hipMemcpyDeviceToDevice, s));
     target->last_stream = s; target->last_valid = true;
-    if (s == target->dev->stream) target->dev->stream_dirty = true;
+    if (s == target->dev->stream) ++target->dev->upload_seq;
     return RND_SUCCESS;
 }
 
@@ -1033,6 +1046,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     /* The box of every draw's vertices, for culling whole draws when the work executes.  A pass of one
      * draw gets none (that draw is the pass).  Draws over the same vertices share one job. */
     cmd->geometry_epoch = dev->geometry_epoch;
+    cmd->index_epoch = dev->index_epoch;
     if (n >= 2) {
         std::vector<BoundsJob> bjobs;
         std::vector<uint32_t> bjob_of(n, 0xFFFFFFFFu);
@@ -1247,6 +1261,10 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     if (cmd->dev != dev) return fail(RND_ERROR_INVALID_ARGUMENT, "command buffer belongs to another device");
     if (cmd->state != CMD_EXECUTABLE) return fail(RND_ERROR_RECORDING, "command buffer is not in the executable state");
     if (int r = set_device(dev)) return r;
+    /* How many vertices a draw transforms is its largest index + 1, scanned when the command buffer was recorded.
+     * Index data written since then may point past that: such a frame would silently drop primitives. */
+    if (cmd->index_epoch != dev->index_epoch && !cmd->draws.empty())
+        return fail(RND_ERROR_RECORDING, "an index buffer was written after this command buffer was recorded: record it again");
     FrameParams fp = cmd->fp;
     fp.shard_index = cmd->shard_index; fp.shard_count = cmd->shard_count;
     /* vertex data written since recording: the boxes no longer bound it, draw everything */
@@ -1258,11 +1276,12 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
 #endif
     hipStream_t s = cmd->stream;
     rnd_target tg = cmd->target;
-    if (s != dev->stream && dev->stream_dirty) {
-        /* uploads and copies queued on the device's stream come first */
+    if (s != dev->stream && cmd->seen_seq != dev->upload_seq) {
+        /* uploads and copies queued on the device's stream come first.  Every command buffer has a stream of
+         * its own, so each one waits for what it has not been ordered behind yet, not only the first to submit. */
         HIP_TRY(hipEventRecord(dev->order_ev, dev->stream));
         HIP_TRY(hipStreamWaitEvent(s, dev->order_ev, 0));
-        dev->stream_dirty = false;
+        cmd->seen_seq = dev->upload_seq;
     }
     if (tg && tg->last_valid) HIP_TRY(wait_for_stream(s, tg->last_stream, tg->order_ev));
     const bool prof = dev->profiling;

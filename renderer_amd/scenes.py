@@ -319,6 +319,16 @@ def config3(width=7680, height=4320, seed=3):
     return instanced_spheres(width, height, 100, 100, 4, seed, True, name="config3_8k")
 
 
+def config4_camera(k, n_views=64):
+    """Camera k of the orbit: eye_k = Ry(2 pi k / n_views) * (0, 0, -2), looking at the origin.  A full turn:
+    view 0 faces the grid, views near n/4 and 3n/4 look along it from inside its extent (everything
+    straddles the near plane or is a sliver), views between them see its back (all culled)."""
+    cam = hm.Camera()
+    ang = 2.0 * np.pi * k / n_views
+    cam.eye_position = np.array([-2.0 * np.sin(ang), 0.0, -2.0 * np.cos(ang)], dtype=F)
+    return cam
+
+
 def config4_view(k, n_views=64, width=1920, height=1080, quads=2237, seed=4, mesh=None):
     """View k of 64 cameras on a y-axis orbit around a 2237x2237-quad grid
     (10 008 338 triangles, 5 008 644 vertices).  Pass `mesh` to reuse the arrays."""
@@ -327,12 +337,7 @@ def config4_view(k, n_views=64, width=1920, height=1080, quads=2237, seed=4, mes
     sc.vbs.append(v)
     sc.ibs.append(i)
     sc.textures.append(_texture(checker_texture(1024, seed)))
-    cam = hm.Camera()
-    ang = 2.0 * np.pi * k / n_views
-    # eye_k = Ry(angle) * (0,0,-2); small orbit amplitude keeps the grid front-facing
-    swing = 0.6 * np.sin(ang)
-    cam.eye_position = np.array([-2.0 * np.sin(swing), 0.0, -2.0 * np.cos(swing)], dtype=F)
-    sc.ubos.append(_ubo_for(width, height, hm.identity(), cam))
+    sc.ubos.append(_ubo_for(width, height, hm.identity(), config4_camera(k, n_views)))
     sc.pipelines.append(default_pipeline(SHADER_TEST_KTX))
     sc.draws.append(dict(pipeline=0, vb=0, vb_offset=0, ib=0, ib_offset=0, ubo=0, texture=0,
                          push=push_block([1, 1, 1, 1], hm.identity()),

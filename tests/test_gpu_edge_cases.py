@@ -572,3 +572,70 @@ def test_error_codes(device):
     assert e.value.code == -12
     cmd.destroy()
     cmd.destroy()  # destroy is idempotent (handlers.hpp:108-113)
+
+
+def test_upload_precedes_every_later_command_buffer(device, oracle):
+    """A small stream-ordered vertex write (a copy queued on the device's stream), then frames of TWO command
+    buffers into two targets: both must see the new vertices, not only the first one submitted."""
+    sc = helpers.soup_scene(160, 96, 40, 5, n_draws=1)
+    moved = sc.vbs[0].copy()
+    moved[:, 0] = -moved[:, 0]  # mirrored mesh: 40 triangles x 3 vertices x 32 B = 3840 B, one staged copy
+    assert moved.nbytes <= 4096
+    r = SceneRunner(sc, device, frames_in_flight=2)
+    try:
+        r.render()
+        r.render()  # both command buffers have run once with the old vertices
+        r.vbs[0].write(moved)
+        a = r.submit()
+        b = r.submit()
+        assert a != b
+        device.wait_idle()
+        frames = [r.targets[a].read(), r.targets[b].read()]
+    finally:
+        r.destroy()
+    sc.vbs[0] = moved
+    oc, od, _ = oracle.render_scene(sc, threads=4)
+    for color, depth in frames:
+        assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
+def test_index_write_after_recording_needs_a_new_recording(device, oracle):
+    """The number of vertices a draw transforms is scanned from its indices at record time: a command buffer
+    recorded before a write into an index buffer refuses to run until it is recorded again."""
+    sc = helpers.soup_scene(128, 80, 30, 9, n_draws=1)
+    r = SceneRunner(sc, device)
+    try:
+        r.render()
+        new_idx = sc.ibs[0][::-1].copy()
+        r.ibs[0].write(new_idx)
+        with pytest.raises(api.RendererError) as e:
+            r.render()
+        assert e.value.code == -12 and "record" in e.value.msg
+        r.record()
+        color, depth = r.render()
+    finally:
+        r.destroy()
+    sc.ibs[0] = new_idx
+    oc, od, _ = oracle.render_scene(sc, threads=4)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
+def test_small_write_into_a_shared_uniform_vertex_buffer_reaches_memory(device, oracle):
+    """A buffer created with UNIFORM | VERTEX usage holds vertices: a small write into it must be an ordinary copy
+    (the held-back uniform path would leave the vertex kernel reading the old bytes)."""
+    sc = helpers.soup_scene(128, 80, 4, 3, n_draws=1)  # 12 vertices = 384 B, below the held-back limit
+    moved = sc.vbs[0].copy()
+    moved[:, 0] = moved[:, 0] * np.float32(0.5)
+    r = SceneRunner(sc, device)
+    try:
+        r.vbs[0].destroy()
+        r.vbs[0] = api.Buffer(device, api.BUFFER_USAGE_VERTEX | api.BUFFER_USAGE_UNIFORM, sc.vbs[0])
+        r.record()
+        r.render()
+        r.vbs[0].write(moved)
+        color, depth = r.render()
+    finally:
+        r.destroy()
+    sc.vbs[0] = moved
+    oc, od, _ = oracle.render_scene(sc, threads=4)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)

@@ -110,8 +110,16 @@ def test_config3_full_bands(device):
     assert sum(kept) >= len(sc.draws) and max(kept) <= len(sc.draws) // 4
 
 
-def test_config4_view_full(device, oracle):
-    """One view of BASELINE configs[4] at full size: 1920x1080 over a 2237x2237-quad grid
-    (10 008 338 triangles, most of them smaller than a pixel)."""
-    mism = compare(scenes.config4_view(5), device, oracle, threads=16)
+_config4_mesh = []
+
+
+@pytest.mark.parametrize("view", [0, 5, 16, 32, 48])
+def test_config4_view_full(device, oracle, view):
+    """Views of BASELINE configs[4] at full size: 1920x1080 over a 2237x2237-quad grid (10 008 338 triangles,
+    most of them smaller than a pixel) from the 64-camera orbit: facing the grid (0), oblique (5), looking
+    along the grid from inside its extent so that it straddles the near plane (16 and 48), and from
+    behind, where every triangle is culled (32)."""
+    if not _config4_mesh:
+        _config4_mesh.append(scenes.noise_grid(2237, 3.3, 1.8, 0.35, 4))
+    mism = compare(scenes.config4_view(view, mesh=_config4_mesh[0]), device, oracle, threads=16)
     assert mism == 0
