@@ -194,6 +194,7 @@ struct rnd_cmd_t {
     DeviceArray<LargeEntry> d_large_list;
     DeviceArray<ClipTri> d_clip_tris;
     DeviceArray<uint32_t> d_tile_count, d_counters;
+    DeviceArray<unsigned long long> d_probe; /* RND_PROBES builds only */
     FrameParams fp = {};
     uint32_t shard_index = 0, shard_count = 1;
     uint64_t geometry_epoch = 0;   /* the device's when the draws' boxes were computed */
@@ -202,6 +203,44 @@ struct rnd_cmd_t {
 
     void release_compiled()
     {
+#ifdef RND_PROBES
+        if (d_probe.ptr) {
+            std::vector<unsigned long long> v(d_probe.count);
+            if (hipMemcpy(v.data(), d_probe.ptr, v.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                double sum[16] = {};
+                size_t rows = 0;
+                for (size_t r = 0; r < v.size() / 16; ++r) {
+                    if (!v[r * 16]) continue;
+                    ++rows;
+                    for (int i = 0; i < 16; ++i) sum[i] += (double)v[r * 16 + i];
+                }
+                if (rows) {
+                    fprintf(stderr, "tile kernel phases (cycles of wave 0, summed over frames, mean over %zu workgroups): ", rows);
+                    for (int i = 0; i < 13; ++i) if (sum[i] > 0) fprintf(stderr, "%d:%.0f ", i, sum[i] / (double)rows);
+                    /* the last frame: first start to last end, and the workgroups' own lifetimes */
+                    unsigned long long t0 = ~0ull, t1 = 0; double life = 0;
+                    std::vector<unsigned long long> starts;
+                    for (size_t r = 0; r < v.size() / 16; ++r) {
+                        if (!v[r * 16]) continue;
+                        t0 = std::min(t0, v[r * 16 + 14]); t1 = std::max(t1, v[r * 16 + 15]);
+                        life += (double)(v[r * 16 + 15] - v[r * 16 + 14]);
+                        starts.push_back(v[r * 16 + 14]);
+                    }
+                    if (const char* dump = getenv("RND_PROBE_DUMP")) {
+                        if (FILE* f = fopen(dump, "w")) {
+                            for (size_t r = 0; r < v.size() / 16; ++r)
+                                if (v[r * 16]) fprintf(f, "%zu %llu %llu %llu %llu\n", r, v[r * 16 + 14] - t0, v[r * 16 + 15] - t0, v[r * 16 + 13] >> 32, v[r * 16 + 13] & 0xFFFFFFFFull);
+                            fclose(f);
+                        }
+                    }
+                    std::sort(starts.begin(), starts.end());
+                    fprintf(stderr, "\n  last frame (100 MHz ticks): span %llu, mean workgroup lifetime %.0f, workgroups resident on average %.0f; start of workgroup #1280 at +%llu, last start at +%llu\n",
+                            t1 - t0, life / (double)rows, life / (double)(t1 - t0), starts.size() > 1280 ? starts[1280] - t0 : 0ull, starts.back() - t0);
+                }
+            }
+        }
+        d_probe.release();
+#endif
         d_draws.release(); d_derived.release(); d_vchunks.release(); d_tchunks.release(); d_textures.release();
         d_svtx.release(); d_svary.release(); d_prim_rec.release(); d_tile_lists.release(); d_large_list.release(); d_clip_tris.release();
         d_tile_count.release(); d_counters.release();
@@ -358,7 +397,9 @@ int texture_alloc(rnd_device dev, uint32_t w, uint32_t h, int32_t format, uint32
     t->sampler = sampler ? *sampler : rnd_sampler_info{RND_FILTER_LINEAR, 0, 0.0f};
     memset(t->level_ptr, 0, sizeof(t->level_ptr));
     for (uint32_t l = 0; l < levels; ++l) {
-        size_t bytes = (size_t)level_dim(w, l) * level_dim(h, l) * 4;
+        /* 16 bytes of slack behind every level: a bilinear sample reads its two columns as one 8-byte load,
+         * which on a level one texel wide reaches four bytes past the last row */
+        size_t bytes = (size_t)level_dim(w, l) * level_dim(h, l) * 4 + 16;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->level_ptr[l]), bytes);
         if (e != hipSuccess) {
             for (uint32_t k = 0; k < l; ++k) (void)hipFree(t->level_ptr[k]);
@@ -1153,6 +1194,10 @@ int rnd_cmd_end(rnd_cmd cmd)
     /* every frame leaves its counters at zero for the next one; the first frame needs them so */
     HIP_TRY(hipMemset(cmd->d_tile_count.ptr, 0, n_tiles * TILE_COUNT_STRIDE * sizeof(uint32_t)));
     HIP_TRY(hipMemset(cmd->d_counters.ptr, 0, CTR_COUNT * sizeof(uint32_t)));
+#ifdef RND_PROBES
+    HIP_TRY(cmd->d_probe.resize(((size_t)tiles_x * (tiles_y + 8) + 64) * 16)); /* the tile kernel's grid is padded to whole groups of eight rows */
+    HIP_TRY(hipMemset(cmd->d_probe.ptr, 0, cmd->d_probe.count * sizeof(unsigned long long)));
+#endif
 
     FrameParams& fp = cmd->fp;
     memset(&fp, 0, sizeof(fp));
@@ -1162,6 +1207,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     fp.tile_count = cmd->d_tile_count.ptr; fp.tile_lists = cmd->d_tile_lists.ptr;
     fp.large_list = cmd->d_large_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
     fp.counters = cmd->d_counters.ptr;
+    fp.probe_cycles = cmd->d_probe.ptr;
     fp.tile_capacity = (uint32_t)tile_cap; fp.tile_stride = (uint32_t)tile_stride; fp.large_capacity = (uint32_t)large_cap;
     fp.clip_tri_capacity = (uint32_t)clip_tri_cap;
     {
@@ -1219,6 +1265,12 @@ int rnd_cmd_end(rnd_cmd cmd)
      * still clears the render area) */
     if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
     fp.direct_index = n == 1 ? 1u : 0u;
+    {
+        /* RND_VTX_CACHE=0 in the environment switches the tile kernel's LDS vertex cache off when a command buffer is
+         * recorded (for timing one path against the other, and so that tests reach the path without it) */
+        const char* sw = getenv("RND_VTX_CACHE");
+        fp.vtx_cache = (tg->samples == 1 && svtx_total <= VC_MAX_VERTEX && !(sw && sw[0] == '0')) ? 1u : 0u;
+    }
     fp.pass_shader = n ? ds[0].shader : -1;
     fp.pass_texture = n ? ds[0].texture : -1;
     for (size_t i = 1; i < n; ++i) {

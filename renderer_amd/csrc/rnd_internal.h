@@ -47,6 +47,20 @@ struct __attribute__((aligned(16))) ShadeTables {
     uint8_t pad[12]; /* size is a multiple of 16 bytes */
 };
 
+/* The tile kernel's per-tile vertex cache (LDS): after rasterisation the corners of the tile's visible primitives are
+ * entered into a hash set of VC_TAGS words, each distinct vertex gets one of VC_RECS 32-byte records, filled once from
+ * device memory, and shading reads its corners from there.  A tag word is vertex << VC_IDX_BITS | record. */
+constexpr uint32_t VC_TAGS = 1024;
+#ifndef VC_RECS
+#define VC_RECS 480
+#endif
+constexpr uint32_t VC_IDX_BITS = 9;
+constexpr uint32_t VC_IDX_NONE = (1u << VC_IDX_BITS) - 1u;       /* no record (yet, or none left) */
+constexpr uint32_t VC_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t VC_MAX_VERTEX = (1u << (32 - VC_IDX_BITS)) - 1u; /* vertex numbers a tag can hold without colliding with VC_EMPTY */
+constexpr int VC_PROBES = 8;
+static_assert(VC_RECS <= VC_IDX_NONE, "record numbers must fit the tag's low bits");
+
 /* Bits of TileEntry::slot_flags and PrimRec::draw_flags */
 constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   /* primitive slot (submission number) */
 constexpr uint32_t ENTRY_SUB_SHIFT = 28;      /* bits 28..30: fan index of a clipped primitive's triangle */
@@ -175,8 +189,20 @@ struct IndexRangeJob {
  * only in a build with -DRND_PROBES (tools/build_variant.sh), which reads the mask from RND_DEBUG. */
 #ifdef RND_PROBES
 #define RND_PROBE(fp, bit) (((fp).debug_flags & (bit)) != 0u)
+/* phase stamps: thread 0 of every workgroup adds the cycles since its previous stamp to slot `i` of the workgroup's own row
+ * (no atomics: a row has one writer) */
+#define RND_STAMP(fp, last, i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0u) { (fp).probe_cycles[(size_t)blockIdx.x * 16 + (i)] += now_ - (last); } (last) = now_; } while (0)
+#define RND_STAMP_START(last) unsigned long long last = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0u) { (fp).probe_cycles[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); \
+            (fp).probe_cycles[(size_t)blockIdx.x * 16 + 13] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | \
+                                                              (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+#define RND_STAMP_END(fp) do { if (threadIdx.x == 0u) (fp).probe_cycles[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define RND_STAMP_END(fp) do { } while (0)
 #define RND_PROBE(fp, bit) false
+#define RND_STAMP(fp, last, i) do { } while (0)
+#define RND_STAMP_START(last) do { } while (0)
 #endif
 
 struct FrameParams {
@@ -224,6 +250,9 @@ struct FrameParams {
     int32_t pass_shader;     /* shader of every draw of the pass, or -1 when they differ */
     int32_t pass_texture;    /* texture index of every draw (-1: none bound), or -2 when they differ */
     TexDesc pass_tex;        /* textures[pass_texture] by value */
+    uint32_t vtx_cache;      /* 1: the tile kernel stages the corners its visible primitives use in LDS (one sample per pixel,
+                                vertex numbers below VC_MAX_VERTEX) */
+    unsigned long long* probe_cycles; /* a build with RND_PROBES: wave-cycles summed per phase of the tile kernel; otherwise null */
     uint32_t debug_flags;    /* probe masks of a build with RND_PROBES (timing experiments; results are wrong); otherwise unused */
 };
 

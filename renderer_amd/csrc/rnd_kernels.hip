@@ -1027,6 +1027,54 @@ __device__ __forceinline__ void linear_taps(const TexView& t, uint32_t level, fl
     tp.off[2] = (row1 + (uint32_t)x0) << 2; tp.off[3] = (row1 + (uint32_t)x1) << 2;
 }
 
+/* The same four texels of a CLAMP_TO_EDGE level as two 8-byte loads, one per row: the two columns a
+ * sample reads are x0 = clamp(i) and x1 = clamp(i + 1), which are both among {b, b + 1} for
+ * b = min(x0, max(w - 2, 0)) -- neighbours in memory.  Half the vector-memory instructions of four
+ * single-texel loads for the same bytes.  A level one texel wide reads four bytes past its row; every
+ * level is allocated with that much slack behind it (texture_alloc) and the extra texel is never
+ * selected.  A REPEAT sampler keeps the four single loads: its second column wraps to the row's start. */
+struct PairTaps {
+    uint32_t row[2];   /* byte offset of column b in the sample's two rows */
+    bool x0_hi, x1_hi; /* which texel of the pair is column x0 / x1 */
+    float ax, ay;
+};
+
+__device__ __forceinline__ void pair_taps(const TexView& t, uint32_t level, float u, float v, PairTaps& tp)
+{
+    const int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
+    float fu = fma32(u, (float)w, -0.5f), fv = fma32(v, (float)h, -0.5f);
+    fu = fminf(fmaxf(fu, -1.0e9f), 1.0e9f);
+    fv = fminf(fmaxf(fv, -1.0e9f), 1.0e9f);
+    const float iu = floorf(fu), iv = floorf(fv);
+    tp.ax = fu - iu; tp.ay = fv - iv;
+    const int i = (int)iu, j = (int)iv;
+    const int x0 = min(max(i, 0), w - 1), x1 = min(max(i + 1, 0), w - 1);
+    const int y0 = min(max(j, 0), h - 1), y1 = min(max(j + 1, 0), h - 1);
+    const int b = min(x0, max(w - 2, 0));
+    tp.x0_hi = x0 != b; tp.x1_hi = x1 != b;
+    tp.row[0] = (__umul24((uint32_t)y0, (uint32_t)w) + (uint32_t)b) << 2;
+    tp.row[1] = (__umul24((uint32_t)y1, (uint32_t)w) + (uint32_t)b) << 2;
+}
+
+/* two neighbouring texels in one load; the address is a multiple of 4, not of 8 */
+struct TexelPair { uint32_t lo, hi; };
+
+__device__ __forceinline__ TexelPair load_texel_pair(const uint8_t* lv, uint32_t byte_offset)
+{
+    typedef unsigned long long __attribute__((aligned(4))) Packed;
+    typedef const __attribute__((address_space(1))) Packed* GlobalPair;
+    const unsigned long long q = *(GlobalPair)(lv + byte_offset);
+    TexelPair r;
+    r.lo = (uint32_t)q; r.hi = (uint32_t)(q >> 32);
+    return r;
+}
+
+__device__ __forceinline__ void pair_select(const PairTaps& tp, const TexelPair& r0, const TexelPair& r1, uint32_t* p)
+{
+    p[0] = tp.x0_hi ? r0.hi : r0.lo; p[1] = tp.x1_hi ? r0.hi : r0.lo;
+    p[2] = tp.x0_hi ? r1.hi : r1.lo; p[3] = tp.x1_hi ? r1.hi : r1.lo;
+}
+
 __device__ __forceinline__ uint32_t nearest_tap(const TexView& t, uint32_t level, float u, float v)
 {
     const int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
@@ -1075,13 +1123,23 @@ __device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexD
         return;
     }
     if (!__ballot(!base_only)) {
-        Taps tp;
-        linear_taps(t, 0, u, v, tp);
         const uint8_t* lv = level_base<PASS_TEX>(desc, lds_levels, 0);
         uint32_t p[4];
+        float ax, ay;
+        if (!t.tiled) {
+            PairTaps tp;
+            pair_taps(t, 0, u, v, tp);
+            const TexelPair r0 = load_texel_pair(lv, tp.row[0]), r1 = load_texel_pair(lv, tp.row[1]);
+            pair_select(tp, r0, r1, p);
+            ax = tp.ax; ay = tp.ay;
+        } else {
+            Taps tp;
+            linear_taps(t, 0, u, v, tp);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[k] = load_texel(lv, tp.off[k]);
-        bilinear(tb, t.table, p, tp.ax, tp.ay, rgb);
+            for (int k = 0; k < 4; ++k) p[k] = load_texel(lv, tp.off[k]);
+            ax = tp.ax; ay = tp.ay;
+        }
+        bilinear(tb, t.table, p, ax, ay, rgb);
         return;
     }
     /* Lanes of one wave usually disagree about base_only.  Rather than run the one-level and the
@@ -1091,19 +1149,32 @@ __device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexD
     const uint32_t lo = (uint32_t)fl;
     const uint32_t hi = base_only ? 0u : (lo + 1 < t.levels ? lo + 1 : t.levels - 1);
     const float frac = base_only ? 0.0f : lambda - fl;
-    Taps ta, tc;
-    linear_taps(t, lo, u, v, ta);
-    linear_taps(t, hi, u, v, tc);
     const uint8_t* la = level_base<PASS_TEX>(desc, lds_levels, lo);
     const uint8_t* lc = level_base<PASS_TEX>(desc, lds_levels, hi);
     uint32_t pa[4], pc[4];
+    float aax, aay, cax, cay;
+    if (!t.tiled) {
+        PairTaps ta, tc;
+        pair_taps(t, lo, u, v, ta);
+        pair_taps(t, hi, u, v, tc);
+        const TexelPair a0 = load_texel_pair(la, ta.row[0]), a1 = load_texel_pair(la, ta.row[1]);
+        const TexelPair c0 = load_texel_pair(lc, tc.row[0]), c1 = load_texel_pair(lc, tc.row[1]);
+        pair_select(ta, a0, a1, pa);
+        pair_select(tc, c0, c1, pc);
+        aax = ta.ax; aay = ta.ay; cax = tc.ax; cay = tc.ay;
+    } else {
+        Taps ta, tc;
+        linear_taps(t, lo, u, v, ta);
+        linear_taps(t, hi, u, v, tc);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pa[k] = load_texel(la, ta.off[k]);
+        for (int k = 0; k < 4; ++k) pa[k] = load_texel(la, ta.off[k]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pc[k] = load_texel(lc, tc.off[k]);
+        for (int k = 0; k < 4; ++k) pc[k] = load_texel(lc, tc.off[k]);
+        aax = ta.ax; aay = ta.ay; cax = tc.ax; cay = tc.ay;
+    }
     float a[3], c[3];
-    bilinear(tb, t.table, pa, ta.ax, ta.ay, a);
-    bilinear(tb, t.table, pc, tc.ax, tc.ay, c);
+    bilinear(tb, t.table, pa, aax, aay, a);
+    bilinear(tb, t.table, pc, cax, cay, c);
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[k] = fma32(frac, c[k] - a[k], a[k]);
 }
@@ -1197,55 +1268,19 @@ __device__ __forceinline__ void to_parent(const float* bary, float* q)
     q[0] = lam[0]; q[1] = lam[1]; q[2] = lam[2];
 }
 
-/* colour of the fragment of (slot, sub) at pixel (x, y) */
-__device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
-                            uint32_t slot, uint32_t sub, bool clipped, int x, int y, float* rgba)
+/* The fragment shader proper: everything after the corners' data are in registers.  c: window positions and
+ * 1/w of the triangle the weights are taken over (a fan triangle when clipped); v0..v2: the vertex shader's
+ * outputs at the PARENT's corners; bary (clipped only): the fan triangle's corners as weights over the parent's. */
+__device__ __forceinline__ void shade_fragment(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels, uint32_t draw,
+                                               int shader, int texture, const Corners& c, const Varyings& v0, const Varyings& v1,
+                                               const Varyings& v2, const float* bary, int x, int y, float* rgba)
 {
-    PrimRec pr;
-    if (fp.direct_index && !clipped) {
-        /* a pass of one draw: the slot is the triangle's number, its corners come from the index buffer */
-        const DrawStatic& d = fp.draws[0];
-        const uint32_t* ip = d.ib + (size_t)slot * 3;
-        pr.v0 = d.svtx_base + load_u32(ip); pr.v1 = d.svtx_base + load_u32(ip + 1); pr.v2 = d.svtx_base + load_u32(ip + 2);
-        pr.draw_flags = 0;
-    } else {
-        pr = fp.prim_rec[slot];
-    }
-    uint32_t vtx[3] = {pr.v0, pr.v1, pr.v2};
-    uint32_t draw = pr.draw_flags & SLOT_MASK;
-    if (clipped) {
-        const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
-        draw = ct->draw;
-        vtx[0] = ct->v[0]; vtx[1] = ct->v[1]; vtx[2] = ct->v[2];
-    }
-    /* shader and texture come from the kernel arguments when every draw of the pass agrees,
-     * which saves two dependent loads per pixel; otherwise from the draw's record */
-    const int shader = fp.pass_shader >= 0 ? fp.pass_shader : fp.draws[draw].shader;
-    int texture = -1;
-    if (shader == 0 || shader == 1) texture = fp.pass_texture != -2 ? fp.pass_texture : fp.draws[draw].texture;
     const bool want_derivs = texture >= 0;
-    Varyings v0, v1, v2;
-    load_varyings(fp, vtx[0], shader, v0);
-    load_varyings(fp, vtx[1], shader, v1);
-    load_varyings(fp, vtx[2], shader, v2);
-
     /* weights over the parent's corners at the pixel centre, and at the neighbour in x and the
      * neighbour in y of the 2x2 quad (same primitive, extrapolated) for the derivatives */
     float lam[3], lnx[3] = {0.f, 0.f, 0.f}, lny[3] = {0.f, 0.f, 0.f};
-    Corners c;
-    if (!clipped) {
-        const SVtx p0 = fp.svtx[vtx[0]], p1 = fp.svtx[vtx[1]], p2 = fp.svtx[vtx[2]];
-        c.x[0] = p0.xf >> 8; c.y[0] = p0.y; c.iw[0] = p0.iw;
-        c.x[1] = p1.xf >> 8; c.y[1] = p1.y; c.iw[1] = p1.iw;
-        c.x[2] = p2.xf >> 8; c.y[2] = p2.y; c.iw[2] = p2.iw;
-    } else {
-        const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { c.x[k] = ct->x[k]; c.y[k] = ct->y[k]; c.iw[k] = ct->iw[k]; }
-    }
     corner_weights(c, x, y, want_derivs, lam, lnx, lny);
-    if (clipped) {
-        const float* bary = fp.clip_tris[pr.v0 + sub].bary;
+    if (bary) {
         to_parent(bary, lam);
         if (want_derivs) { to_parent(bary, lnx); to_parent(bary, lny); }
     }
@@ -1278,6 +1313,58 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
         rgba[0] = c0 * diff; rgba[1] = c1 * diff; rgba[2] = c2 * diff;
     }
     rgba[3] = 1.0f;
+}
+
+/* shader and texture of a draw: from the kernel arguments when every draw of the pass agrees, which
+ * saves two dependent loads per pixel; otherwise from the draw's record */
+__device__ __forceinline__ void shader_and_texture(const FrameParams& fp, uint32_t draw, int& shader, int& texture)
+{
+    shader = fp.pass_shader >= 0 ? fp.pass_shader : fp.draws[draw].shader;
+    texture = -1;
+    if (shader == 0 || shader == 1) texture = fp.pass_texture != -2 ? fp.pass_texture : fp.draws[draw].texture;
+}
+
+/* colour of the fragment of (slot, sub) at pixel (x, y), everything gathered from device memory */
+__device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
+                            uint32_t slot, uint32_t sub, bool clipped, int x, int y, float* rgba)
+{
+    PrimRec pr;
+    if (fp.direct_index && !clipped) {
+        /* a pass of one draw: the slot is the triangle's number, its corners come from the index buffer */
+        const DrawStatic& d = fp.draws[0];
+        const uint32_t* ip = d.ib + (size_t)slot * 3;
+        pr.v0 = d.svtx_base + load_u32(ip); pr.v1 = d.svtx_base + load_u32(ip + 1); pr.v2 = d.svtx_base + load_u32(ip + 2);
+        pr.draw_flags = 0;
+    } else {
+        pr = fp.prim_rec[slot];
+    }
+    uint32_t vtx[3] = {pr.v0, pr.v1, pr.v2};
+    uint32_t draw = pr.draw_flags & SLOT_MASK;
+    if (clipped) {
+        const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
+        draw = ct->draw;
+        vtx[0] = ct->v[0]; vtx[1] = ct->v[1]; vtx[2] = ct->v[2];
+    }
+    int shader, texture;
+    shader_and_texture(fp, draw, shader, texture);
+    Varyings v0, v1, v2;
+    load_varyings(fp, vtx[0], shader, v0);
+    load_varyings(fp, vtx[1], shader, v1);
+    load_varyings(fp, vtx[2], shader, v2);
+    Corners c;
+    const float* bary = nullptr;
+    if (!clipped) {
+        const SVtx p0 = fp.svtx[vtx[0]], p1 = fp.svtx[vtx[1]], p2 = fp.svtx[vtx[2]];
+        c.x[0] = p0.xf >> 8; c.y[0] = p0.y; c.iw[0] = p0.iw;
+        c.x[1] = p1.xf >> 8; c.y[1] = p1.y; c.iw[1] = p1.iw;
+        c.x[2] = p2.xf >> 8; c.y[2] = p2.y; c.iw[2] = p2.iw;
+    } else {
+        const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { c.x[k] = ct->x[k]; c.y[k] = ct->y[k]; c.iw[k] = ct->iw[k]; }
+        bary = ct->bary;
+    }
+    shade_fragment(fp, tb, pass_levels, draw, shader, texture, c, v0, v1, v2, bary, x, y, rgba);
 }
 
 __device__ __forceinline__ uint32_t pack_color(const FrameParams& fp, const ShadeTables& tb, const float* rgba)
@@ -1396,6 +1483,183 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
     reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, acc);
 }
 
+/* ---- per-tile vertex cache ---- */
+
+struct VtxCache {
+    uint32_t tags[VC_TAGS];     /* hash set of vertex numbers: vertex << VC_IDX_BITS | record, or VC_EMPTY */
+    uint4 recs[VC_RECS * 2];    /* record r: {x24.8 << 8 | outcode, y24.8, 1/w, u} {nx, ny, nz, v}; word 0 holds the vertex number until the record is filled */
+    uint32_t count;             /* records handed out (may run past VC_RECS: the surplus vertices stay uncached) */
+    uint32_t pad[3];
+};
+
+constexpr uint32_t VC_POS_BITS = 10;
+constexpr uint32_t VC_PIXEL_UNCACHED = 1u << 31; /* in a pixel's packed hash positions: some corner has no record */
+static_assert((1u << VC_POS_BITS) == VC_TAGS, "a hash position is VC_POS_BITS wide");
+
+/* Enters vertex v into the set (lanes with want == false only take part in the wave-wide steps).  Returns the
+ * position of its tag word, or VC_TAGS when VC_PROBES positions were all taken by other vertices.  The lane that
+ * claims an empty position hands the vertex a record number (one LDS add per wave and round: ballot + popcount) and
+ * leaves the vertex number in the record for the fill. */
+__device__ __forceinline__ uint32_t vc_insert(VtxCache& vc, uint32_t v, bool want)
+{
+    uint32_t h = (v * 0x9E3779B1u) >> (32 - VC_POS_BITS);
+    uint32_t pos = VC_TAGS;
+    bool pending = want;
+    const uint32_t lane = lane_id();
+#pragma unroll 1
+    for (int probe = 0; probe < VC_PROBES; ++probe) {
+        if (!__ballot(pending)) break;
+        uint32_t old = 0u;
+        if (pending) old = atomicCAS(&vc.tags[h], VC_EMPTY, (v << VC_IDX_BITS) | VC_IDX_NONE);
+        const bool won = pending && old == VC_EMPTY;
+        const bool same = pending && old != VC_EMPTY && (old >> VC_IDX_BITS) == v;
+        const uint64_t winners = __ballot(won);
+        if (winners) {
+            const int leader = __ffsll((unsigned long long)winners) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&vc.count, (uint32_t)__popcll(winners));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (won) {
+                const uint32_t rec = base + (uint32_t)__popcll(winners & ((1ull << lane) - 1ull));
+                if (rec < VC_RECS) {
+                    vc.tags[h] = (v << VC_IDX_BITS) | rec;
+                    vc.recs[rec * 2].x = v;
+                }
+            }
+        }
+        if (won || same) { pos = h; pending = false; }
+        else if (pending) h = (h + 1u) & (VC_TAGS - 1u);
+    }
+    return pos;
+}
+
+/* After rasterisation: every thread takes four of the tile's pixels, stores their depth words, finds the three
+ * corners of each pixel's owner (index buffer or primitive record: one load per pixel, the four in flight together)
+ * and enters them into the set.  The pixel's word in `keys` then becomes owner | packed hash positions << 32. */
+__device__ __forceinline__ void vc_collect(const FrameParams& fp, const TileCtx& tc, VtxCache& vc, unsigned long long clear_key)
+{
+    uint32_t vis[4], vtx[4][3];
+    bool use[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p = threadIdx.x + (uint32_t)j * TILE_THREADS;
+        const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
+        const bool inside = x >= fp.area_x0 && x <= fp.area_x1 && y >= fp.area_y0 && y <= fp.area_y1;
+        const unsigned long long k = tc.keys[p];
+        vis[j] = VIS_NONE;
+        if (inside) {
+            fp.depth[(size_t)y * fp.width + (size_t)x] = fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24;
+            if (k != clear_key) {
+                const uint32_t low = (uint32_t)(k >> 8);
+                vis[j] = ((fp.depth_less ? low : ~low) & SLOT_MASK) | ((uint32_t)(k & 15ull) << ENTRY_SUB_SHIFT);
+            }
+        }
+        /* a clipped primitive's corners live in its fan triangles' records: such pixels take the uncached path */
+        use[j] = vis[j] != VIS_NONE && !(vis[j] & FLAG_CLIPPED);
+        vtx[j][0] = vtx[j][1] = vtx[j][2] = 0u;
+    }
+    if (fp.direct_index) {
+        const DrawStatic& d = fp.draws[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!use[j]) continue;
+            const uint32_t* ip = d.ib + (size_t)(vis[j] & SLOT_MASK) * 3;
+            vtx[j][0] = d.svtx_base + load_u32(ip); vtx[j][1] = d.svtx_base + load_u32(ip + 1); vtx[j][2] = d.svtx_base + load_u32(ip + 2);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!use[j]) continue;
+            const PrimRec pr = fp.prim_rec[vis[j] & SLOT_MASK];
+            vtx[j][0] = pr.v0; vtx[j][1] = pr.v1; vtx[j][2] = pr.v2;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t packed = 0u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t pos = vc_insert(vc, vtx[j][c], use[j]);
+            if (pos >= VC_TAGS) packed |= VC_PIXEL_UNCACHED;
+            packed |= (pos & (VC_TAGS - 1u)) << (VC_POS_BITS * c);
+        }
+        if (!use[j]) packed = VC_PIXEL_UNCACHED;
+        tc.keys[threadIdx.x + (uint32_t)j * TILE_THREADS] = ((unsigned long long)packed << 32) | vis[j];
+    }
+}
+
+/* Every record handed out is filled once, one thread per vertex: the screen-space vertex and the vertex shader's
+ * other outputs, 36 bytes from device memory into 32 bytes of LDS (depth is not needed for shading). */
+__device__ __forceinline__ void vc_fill(const FrameParams& fp, VtxCache& vc)
+{
+    const uint32_t n = min(vc.count, (uint32_t)VC_RECS);
+    for (uint32_t r = threadIdx.x; r < n; r += TILE_THREADS) {
+        const uint32_t v = vc.recs[r * 2].x;
+        const SVtx sv = fp.svtx[v];
+        const float4* rec = reinterpret_cast<const float4*>(&fp.svary[v]);
+        const float4 a = rec[0];
+        const float vv = reinterpret_cast<const float*>(rec)[4];
+        vc.recs[r * 2] = make_uint4((uint32_t)sv.xf, (uint32_t)sv.y, __float_as_uint(sv.iw), __float_as_uint(a.w));
+        vc.recs[r * 2 + 1] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(vv));
+    }
+}
+
+__device__ __forceinline__ void vc_corner(const VtxCache& vc, uint32_t rec, int shader, int k, Corners& c, Varyings& out)
+{
+    const uint4 a = vc.recs[rec * 2], b = vc.recs[rec * 2 + 1];
+    c.x[k] = (int32_t)a.x >> 8; c.y[k] = (int32_t)a.y; c.iw[k] = __uint_as_float(a.z);
+    out.n[0] = __uint_as_float(b.x); out.n[1] = __uint_as_float(b.y); out.n[2] = __uint_as_float(b.z);
+    out.uv[0] = __uint_as_float(a.w);
+    const float v = __uint_as_float(b.w);
+    out.uv[1] = shader == 0 ? 1.0f - v : v; /* dummy.vert.glsl:25 flips v */
+}
+
+/* The shading phase with the cache: the pixel's word holds its owner and where its corners' tags are. */
+__device__ __forceinline__ void vc_shade(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels, const TileCtx& tc,
+                                         const VtxCache& vc)
+{
+    for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
+        const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
+        if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
+        const size_t pi = (size_t)y * fp.width + (size_t)x;
+        const unsigned long long word = tc.keys[p];
+        const uint32_t owner = (uint32_t)word, packed = (uint32_t)(word >> 32);
+        if (owner == VIS_NONE) { reinterpret_cast<uint32_t*>(fp.color)[pi] = fp.clear_packed; continue; }
+        uint32_t rec[3] = {VC_IDX_NONE, VC_IDX_NONE, VC_IDX_NONE};
+        if (!(packed & VC_PIXEL_UNCACHED)) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rec[c] = vc.tags[(packed >> (VC_POS_BITS * c)) & (VC_TAGS - 1u)] & VC_IDX_NONE;
+        }
+        float rgba[4];
+        if (rec[0] != VC_IDX_NONE && rec[1] != VC_IDX_NONE && rec[2] != VC_IDX_NONE) {
+            /* which draw: only a pass whose draws differ in shader, texture or (push-constant shader) colour needs it */
+            uint32_t draw = 0u;
+            if (!fp.direct_index && (fp.pass_shader < 0 || fp.pass_shader == 2 || fp.pass_texture == -2))
+                draw = fp.prim_rec[owner & SLOT_MASK].draw_flags & SLOT_MASK;
+            int shader, texture;
+            shader_and_texture(fp, draw, shader, texture);
+            Corners c;
+            Varyings v0, v1, v2;
+            vc_corner(vc, rec[0], shader, 0, c, v0);
+            vc_corner(vc, rec[1], shader, 1, c, v1);
+            vc_corner(vc, rec[2], shader, 2, c, v2);
+            shade_fragment(fp, tb, pass_levels, draw, shader, texture, c, v0, v1, v2, nullptr, x, y, rgba);
+        } else {
+            shade_pixel(fp, tb, pass_levels, owner & SLOT_MASK, (owner >> ENTRY_SUB_SHIFT) & 7u, (owner & FLAG_CLIPPED) != 0u, x, y, rgba);
+        }
+        reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, rgba);
+    }
+}
+
+/* The cache is a build option: its LDS (32 KB per workgroup with VC_RECS = 480) is allocated whether a pass uses it or not. */
+#ifndef RND_VTX_CACHE_BUILD
+#define RND_VTX_CACHE_BUILD 0
+#endif
+template <int S> struct CacheStore { uint32_t unused; };
+#if RND_VTX_CACHE_BUILD
+template <> struct CacheStore<1> { VtxCache vc; };
+#endif
+
 /* One workgroup per 32x32 tile, in two phases.  Rasterise the tile's triangles into one 64-bit
  * word per sample held in LDS (depth, submission order, fan index; the minimum wins).  Then every
  * thread takes the tile's pixels one row of eight at a time: depth word and owner of each sample
@@ -1411,6 +1675,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     __shared__ unsigned long long keys[TILE_PIXELS * S];
     __shared__ ShadeTables tb;
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
+    __shared__ CacheStore<S> cache_store; /* the vertex cache exists only in the one-sample kernel */
     uint32_t tile, utx, uty;
     if (fp.shard_count == 1) {
         /* the grid covers the tiles the render area touches */
@@ -1428,6 +1693,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     tc.rx0 = max(tc.px0, fp.clamp_x0); tc.ry0 = max(tc.py0, fp.clamp_y0);
     tc.rx1 = min(tc.px0 + TILE_W - 1, fp.clamp_x1); tc.ry1 = min(tc.py0 + TILE_H - 1, fp.clamp_y1);
     tc.keys = keys;
+    RND_STAMP_START(stamp);
 
     /* the length of the tile's list is asked for first: its round trip runs under the staging of
      * the tables and the clearing of the tile's words */
@@ -1439,7 +1705,14 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
     for (uint32_t i = threadIdx.x; i < TILE_PIXELS * S; i += TILE_THREADS) keys[i] = clear_key;
+    if constexpr (S == 1 && RND_VTX_CACHE_BUILD) {
+        if (fp.vtx_cache) {
+            for (uint32_t i = threadIdx.x; i < VC_TAGS; i += TILE_THREADS) cache_store.vc.tags[i] = VC_EMPTY;
+            if (threadIdx.x == 0) cache_store.vc.count = 0u;
+        }
+    }
     __syncthreads();
+    RND_STAMP(fp, stamp, 0); /* prologue */
 
     if (visible && !RND_PROBE(fp, 2u)) {
         /* this tile's list: 16-byte entries, one per lane per batch */
@@ -1457,6 +1730,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
             return tx >= bx0 && tx <= bx1 && ty >= by0 && ty <= by1;
         });
     }
+    RND_STAMP(fp, stamp, 1); /* rasterisation */
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t ovf = fp.counters[CTR_OVERFLOW];
         if (ovf) fp.status_host[0] = ovf; /* a list overflowed: the host reports it at the next wait */
@@ -1464,7 +1738,25 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     __syncthreads();
     /* every thread has read the list length: leave the counter clean for the next frame's binning */
     if (threadIdx.x == 0) fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE] = 0;
+    RND_STAMP(fp, stamp, 2); /* waiting for the other waves' rasterisation */
 
+    if constexpr (S == 1 && RND_VTX_CACHE_BUILD) {
+        if (fp.vtx_cache) {
+            VtxCache& vc = cache_store.vc;
+            vc_collect(fp, tc, vc, clear_key);
+            RND_STAMP(fp, stamp, 3);
+            __syncthreads();
+            RND_STAMP(fp, stamp, 4);
+            vc_fill(fp, vc);
+            RND_STAMP(fp, stamp, 5);
+            __syncthreads();
+            RND_STAMP(fp, stamp, 6);
+            vc_shade(fp, tb, (LdsLevels)pass_levels, tc, vc);
+            RND_STAMP(fp, stamp, 7);
+            RND_STAMP_END(fp);
+            return;
+        }
+    }
     for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
         const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
         if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
@@ -1482,6 +1774,8 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
         }
         shade_and_store<S>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);
     }
+    RND_STAMP(fp, stamp, 8); /* shading without the cache */
+    RND_STAMP_END(fp);
 }
 
 /* ------------------------------------------------------------------ mip generation (blit LINEAR, tools.cpp:670-707) */
