@@ -216,6 +216,32 @@ int rnd_cmd_visible_draws(rnd_cmd cmd, uint32_t* out_count);
  * caller-supplied stream, which then carries everything.  fence may be NULL. */
 int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory at the moment they draw -- code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: one render pass holding one indexed draw,
+ * queued at once on the device's stream, with the same result as recording that pass (begin_pass, set_viewport,
+ * set_scissor, bind_*, push_constants, draw_indexed, end) and submitting it.  rnd_cmd_end allocates the buffers a frame's
+ * kernels hand to one another; this call keeps them in one static device array of the library instead (about 25 MiB,
+ * held by every GPU the library runs on until the process ends) and calls no hipMalloc, hipFree or any routine that
+ * allocates.  The buffers, texture, pipeline and target are created beforehand as usual.
+ * Limits (beyond them the call fails with RND_ERROR_OUT_OF_DEVICE_MEMORY and draws nothing): vertex_count <= 65 536,
+ * index_count / 3 <= 131 072, a target of at most 1024 tiles of 32x32 pixels (1280x720 has 920).  Indices >= vertex_count
+ * drop their primitive.  The render area is the whole target.
+ * Every call on a GPU shares that GPU's array: calls run one after the other on the device's stream, and two devices
+ * objects on one GPU (or a caller-supplied stream per device) must not have such calls in flight together. */
+typedef struct rnd_noalloc_draw {
+    rnd_target target;
+    rnd_pipeline pipeline;
+    rnd_texture texture;            /* may be NULL */
+    rnd_buffer vertex_buffer; uint64_t vertex_offset_bytes; uint32_t vertex_count;
+    rnd_buffer index_buffer; uint64_t index_offset_bytes; uint32_t index_count;
+    const float* uniform_block;     /* host memory, 80 floats: projection, view_projection, view, model, mvp */
+    const float* push_constants;    /* host memory, 20 floats (vec4 colour, mat4 transform), or NULL for zeros */
+    float clear_color[4]; float clear_depth;
+    float viewport[6];              /* x, y, width, height, min_depth, max_depth */
+    int32_t scissor[4];             /* x, y, width, height */
+} rnd_noalloc_draw;
+int rnd_draw_indexed_noalloc(rnd_device dev, const rnd_noalloc_draw* draw, rnd_fence fence);
+
 int rnd_fence_create(rnd_device dev, rnd_fence* out);  /* vk_app.cpp:109-130 */
 int rnd_fence_wait(rnd_fence fence);                   /* vkWaitForFences vk_app.cpp:435-442 */
 int rnd_fence_destroy(rnd_fence fence);

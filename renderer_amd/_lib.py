@@ -24,7 +24,7 @@ SYMBOLS = [
     "rnd_cmd_bind_pipeline", "rnd_cmd_bind_vertex_buffer", "rnd_cmd_bind_index_buffer", "rnd_cmd_bind_uniform",
     "rnd_cmd_bind_texture", "rnd_cmd_push_constants", "rnd_cmd_draw_indexed", "rnd_cmd_end_pass", "rnd_cmd_end",
     "rnd_cmd_destroy", "rnd_cmd_set_tile_shard", "rnd_cmd_visible_draws",
-    "rnd_submit",
+    "rnd_submit", "rnd_draw_indexed_noalloc",
     "rnd_fence_create", "rnd_fence_wait", "rnd_fence_destroy",
 ]
 
@@ -45,6 +45,18 @@ class PipelineInfo(C.Structure):
         ("cull_mode", C.c_int32), ("front_face", C.c_int32),
         ("depth_test", C.c_int32), ("depth_write", C.c_int32), ("depth_compare", C.c_int32),
         ("samples", C.c_uint32), ("color_write_mask", C.c_uint32), ("blend_enable", C.c_int32),
+    ]
+
+
+class NoAllocDraw(C.Structure):
+    """rnd_noalloc_draw"""
+    _fields_ = [
+        ("target", C.c_void_p), ("pipeline", C.c_void_p), ("texture", C.c_void_p),
+        ("vertex_buffer", C.c_void_p), ("vertex_offset_bytes", C.c_uint64), ("vertex_count", C.c_uint32),
+        ("index_buffer", C.c_void_p), ("index_offset_bytes", C.c_uint64), ("index_count", C.c_uint32),
+        ("uniform_block", C.POINTER(C.c_float)), ("push_constants", C.POINTER(C.c_float)),
+        ("clear_color", C.c_float * 4), ("clear_depth", C.c_float),
+        ("viewport", C.c_float * 6), ("scissor", C.c_int32 * 4),
     ]
 
 
@@ -106,6 +118,7 @@ def load():
         "rnd_cmd_set_tile_shard": (C.c_int, [vp, u32, u32]),
         "rnd_cmd_visible_draws": (C.c_int, [vp, C.POINTER(u32)]),
         "rnd_submit": (C.c_int, [vp, vp, vp]),
+        "rnd_draw_indexed_noalloc": (C.c_int, [vp, C.POINTER(NoAllocDraw), vp]),
         "rnd_fence_create": (C.c_int, [vp, C.POINTER(vp)]),
         "rnd_fence_wait": (C.c_int, [vp]),
         "rnd_fence_destroy": (C.c_int, [vp]),

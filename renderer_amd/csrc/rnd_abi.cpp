@@ -81,6 +81,8 @@ struct rnd_device_t {
     bool stage_used[STAGE_SLOTS] = {};
     int stage_next = 0;
     uint32_t* status_host = nullptr; /* pinned word the tile kernel writes when a work list overflowed */
+    uint32_t* status_dev = nullptr;  /* the same word as the device addresses it */
+    uint8_t* scratch = nullptr;      /* this device's copy of the library's static scratch array (rnd_draw_indexed_noalloc) */
     /* The latest small write to a uniform buffer.  It never goes to memory by itself: every
      * submit from then on carries it in its kernel arguments and the vertex kernel reads the
      * buffer through it, so frames in flight each see the bytes that were current at their
@@ -387,6 +389,64 @@ uint32_t host_depth24(float z)
     return d > 0xFFFFFFu ? 0xFFFFFFu : d;
 }
 
+/* What a frame's kernels need to know about the pass itself -- the target, the render area and the tiles it touches,
+ * viewport and scissor, the clear values and the depth state -- as opposed to its draws.  Shared by command recording
+ * and by the entry point that allocates nothing. */
+void pass_params(FrameParams& fp, rnd_device dev, rnd_target tg, const int32_t area[4], bool has_viewport_and_scissor, const float* vp,
+                 const int32_t* scissor, const float* clear_color, float clear_depth, int depth_test, int depth_less)
+{
+    fp.status_host = dev->status_dev;
+    fp.color = tg->color; fp.depth = tg->depth;
+    fp.tables = dev->tables;
+    fp.width = tg->width; fp.height = tg->height; fp.samples = tg->samples;
+    fp.color_srgb = format_is_srgb(tg->color_format) ? 1u : 0u;
+    fp.color_bgra = (tg->color_format == RND_FORMAT_B8G8R8A8_SRGB || tg->color_format == RND_FORMAT_B8G8R8A8_UNORM) ? 1u : 0u;
+    fp.tiles_x = (tg->width + TILE_W - 1) / TILE_W; fp.tiles_y = (tg->height + TILE_H - 1) / TILE_H;
+    fp.shard_index = 0; fp.shard_count = 1;
+    fp.area_x0 = area[0]; fp.area_y0 = area[1];
+    fp.area_x1 = area[0] + area[2] - 1; fp.area_y1 = area[1] + area[3] - 1;
+    {
+        /* tiles the render area touches */
+        const int64_t ax0 = std::max<int64_t>(fp.area_x0, 0), ay0 = std::max<int64_t>(fp.area_y0, 0);
+        const int64_t ax1 = std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1), ay1 = std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1);
+        if (ax0 <= ax1 && ay0 <= ay1) {
+            fp.grid_x0 = (uint32_t)(ax0 / TILE_W); fp.grid_y0 = (uint32_t)(ay0 / TILE_H);
+            fp.grid_w = (uint32_t)(ax1 / TILE_W) - fp.grid_x0 + 1; fp.grid_h = (uint32_t)(ay1 / TILE_H) - fp.grid_y0 + 1;
+        }
+    }
+    fp.cull_lo_x = fp.cull_lo_y = -INFINITY; fp.cull_hi_x = fp.cull_hi_y = INFINITY;
+    if (has_viewport_and_scissor) {
+        fp.half_w = vp[2] * 0.5f; fp.half_h = vp[3] * 0.5f;
+        fp.ox = vp[0] + fp.half_w; fp.oy = vp[1] + fp.half_h;
+        fp.pz = vp[5] - vp[4]; fp.zmin = vp[4];
+        /* fragments land only on pixels whose centre is inside viewport, scissor and render area */
+        int vx0 = (int)ceilf(vp[0] - 0.5f), vy0 = (int)ceilf(vp[1] - 0.5f);
+        int vx1 = (int)ceilf(vp[0] + vp[2] - 0.5f) - 1, vy1 = (int)ceilf(vp[1] + vp[3] - 0.5f) - 1;
+        fp.clamp_x0 = std::max(std::max(vx0, scissor[0]), std::max(area[0], 0));
+        fp.clamp_y0 = std::max(std::max(vy0, scissor[1]), std::max(area[1], 0));
+        int64_t sx1 = (int64_t)scissor[0] + scissor[2] - 1, sy1 = (int64_t)scissor[1] + scissor[3] - 1;
+        fp.clamp_x1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vx1, sx1), std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1));
+        fp.clamp_y1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vy1, sy1), std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1));
+        /* the rectangle grown by a pixel, in normalised device coordinates (window = ndc * half + origin) */
+        if (fp.half_w > 0.0f && fp.clamp_x0 <= fp.clamp_x1) {
+            fp.cull_lo_x = ((float)fp.clamp_x0 - 1.0f - fp.ox) / fp.half_w;
+            fp.cull_hi_x = ((float)fp.clamp_x1 + 2.0f - fp.ox) / fp.half_w;
+        }
+        if (fp.half_h > 0.0f && fp.clamp_y0 <= fp.clamp_y1) {
+            fp.cull_lo_y = ((float)fp.clamp_y0 - 1.0f - fp.oy) / fp.half_h;
+            fp.cull_hi_y = ((float)fp.clamp_y1 + 2.0f - fp.oy) / fp.half_h;
+        }
+    } else {
+        fp.clamp_x0 = 0; fp.clamp_y0 = 0; fp.clamp_x1 = -1; fp.clamp_y1 = -1;
+    }
+    memcpy(fp.clear_color, clear_color, 16);
+    fp.clear_packed = host_pack_color(dev->host_tables, clear_color, fp.color_srgb != 0, fp.color_bgra != 0);
+    fp.clear_d24 = host_depth24(clear_depth);
+    fp.depth_test = (uint32_t)depth_test;
+    fp.depth_write = (uint32_t)depth_test;
+    fp.depth_less = (uint32_t)depth_less;
+}
+
 int texture_alloc(rnd_device dev, uint32_t w, uint32_t h, int32_t format, uint32_t levels, const rnd_sampler_info* sampler,
                   rnd_texture* out)
 {
@@ -467,8 +527,14 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&dev->status_host), 64, hipHostMallocDefault);
     if (e == hipSuccess) {
         memset(dev->status_host, 0, 64);
-        e = hipEventCreateWithFlags(&dev->order_ev, hipEventDisableTiming);
+        void* dp = nullptr;
+        e = hipHostGetDevicePointer(&dp, dev->status_host, 0);
+        dev->status_dev = static_cast<uint32_t*>(dp);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&dev->order_ev, hipEventDisableTiming);
+    /* every GPU holds its own copy of the static scratch array at its own address: asked for once per device, here,
+     * with that device current */
+    if (e == hipSuccess) { void* sp = nullptr; e = noalloc_scratch_address(&sp); dev->scratch = static_cast<uint8_t*>(sp); }
     if (e != hipSuccess) {
         rnd_device_destroy(dev);
         return fail(e == hipErrorOutOfMemory ? RND_ERROR_OUT_OF_DEVICE_MEMORY : RND_ERROR_DEVICE_LOST,
@@ -1210,57 +1276,10 @@ int rnd_cmd_end(rnd_cmd cmd)
     fp.probe_cycles = cmd->d_probe.ptr;
     fp.tile_capacity = (uint32_t)tile_cap; fp.tile_stride = (uint32_t)tile_stride; fp.large_capacity = (uint32_t)large_cap;
     fp.clip_tri_capacity = (uint32_t)clip_tri_cap;
-    {
-        void* dp = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&dp, dev->status_host, 0));
-        fp.status_host = static_cast<uint32_t*>(dp);
-    }
-    fp.color = tg->color; fp.depth = tg->depth;
-    fp.tables = dev->tables;
     fp.n_draws = (uint32_t)n; fp.n_vchunks = (uint32_t)vchunks.size(); fp.n_tchunks = (uint32_t)tchunks.size();
     fp.n_textures = (uint32_t)td.size();
-    fp.width = tg->width; fp.height = tg->height; fp.samples = tg->samples;
-    fp.color_srgb = format_is_srgb(tg->color_format) ? 1u : 0u;
-    fp.color_bgra = (tg->color_format == RND_FORMAT_B8G8R8A8_SRGB || tg->color_format == RND_FORMAT_B8G8R8A8_UNORM) ? 1u : 0u;
-    fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
-    fp.shard_index = 0; fp.shard_count = 1;
-    fp.area_x0 = cmd->area[0]; fp.area_y0 = cmd->area[1];
-    fp.area_x1 = cmd->area[0] + cmd->area[2] - 1; fp.area_y1 = cmd->area[1] + cmd->area[3] - 1;
-    {
-        /* tiles the render area touches */
-        const int64_t ax0 = std::max<int64_t>(fp.area_x0, 0), ay0 = std::max<int64_t>(fp.area_y0, 0);
-        const int64_t ax1 = std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1), ay1 = std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1);
-        if (ax0 <= ax1 && ay0 <= ay1) {
-            fp.grid_x0 = (uint32_t)(ax0 / TILE_W); fp.grid_y0 = (uint32_t)(ay0 / TILE_H);
-            fp.grid_w = (uint32_t)(ax1 / TILE_W) - fp.grid_x0 + 1; fp.grid_h = (uint32_t)(ay1 / TILE_H) - fp.grid_y0 + 1;
-        }
-    }
-    fp.cull_lo_x = fp.cull_lo_y = -INFINITY; fp.cull_hi_x = fp.cull_hi_y = INFINITY;
-    if (cmd->has_viewport && cmd->has_scissor) {
-        const float* vp = cmd->viewport;
-        fp.half_w = vp[2] * 0.5f; fp.half_h = vp[3] * 0.5f;
-        fp.ox = vp[0] + fp.half_w; fp.oy = vp[1] + fp.half_h;
-        fp.pz = vp[5] - vp[4]; fp.zmin = vp[4];
-        /* fragments land only on pixels whose centre is inside viewport, scissor and render area */
-        int vx0 = (int)ceilf(vp[0] - 0.5f), vy0 = (int)ceilf(vp[1] - 0.5f);
-        int vx1 = (int)ceilf(vp[0] + vp[2] - 0.5f) - 1, vy1 = (int)ceilf(vp[1] + vp[3] - 0.5f) - 1;
-        fp.clamp_x0 = std::max(std::max(vx0, cmd->scissor[0]), std::max(cmd->area[0], 0));
-        fp.clamp_y0 = std::max(std::max(vy0, cmd->scissor[1]), std::max(cmd->area[1], 0));
-        int64_t sx1 = (int64_t)cmd->scissor[0] + cmd->scissor[2] - 1, sy1 = (int64_t)cmd->scissor[1] + cmd->scissor[3] - 1;
-        fp.clamp_x1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vx1, sx1), std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1));
-        fp.clamp_y1 = (int32_t)std::min<int64_t>(std::min<int64_t>(vy1, sy1), std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1));
-        /* the rectangle grown by a pixel, in normalised device coordinates (window = ndc * half + origin) */
-        if (fp.half_w > 0.0f && fp.clamp_x0 <= fp.clamp_x1) {
-            fp.cull_lo_x = ((float)fp.clamp_x0 - 1.0f - fp.ox) / fp.half_w;
-            fp.cull_hi_x = ((float)fp.clamp_x1 + 2.0f - fp.ox) / fp.half_w;
-        }
-        if (fp.half_h > 0.0f && fp.clamp_y0 <= fp.clamp_y1) {
-            fp.cull_lo_y = ((float)fp.clamp_y0 - 1.0f - fp.oy) / fp.half_h;
-            fp.cull_hi_y = ((float)fp.clamp_y1 + 2.0f - fp.oy) / fp.half_h;
-        }
-    } else {
-        fp.clamp_x0 = 0; fp.clamp_y0 = 0; fp.clamp_x1 = -1; fp.clamp_y1 = -1;
-    }
+    pass_params(fp, dev, tg, cmd->area, cmd->has_viewport && cmd->has_scissor, cmd->viewport, cmd->scissor, cmd->clear_color, cmd->clear_depth,
+                depth_test, depth_less);
     /* an empty rectangle takes no fragment: the geometry kernels are not launched at all (the tile kernel
      * still clears the render area) */
     if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
@@ -1278,12 +1297,6 @@ int rnd_cmd_end(rnd_cmd cmd)
         if (ds[i].texture != fp.pass_texture) fp.pass_texture = -2;
     }
     if (fp.pass_texture >= 0) fp.pass_tex = td[(size_t)fp.pass_texture];
-    memcpy(fp.clear_color, cmd->clear_color, 16);
-    fp.clear_packed = host_pack_color(dev->host_tables, cmd->clear_color, fp.color_srgb != 0, fp.color_bgra != 0);
-    fp.clear_d24 = host_depth24(cmd->clear_depth);
-    fp.depth_test = (uint32_t)depth_test;
-    fp.depth_write = (uint32_t)depth_test;
-    fp.depth_less = (uint32_t)depth_less;
     cmd->state = CMD_EXECUTABLE;
     return RND_SUCCESS;
 }
@@ -1349,6 +1362,114 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
         cmd->submitted = true;
         if (tg) { tg->last_stream = s; tg->last_valid = true; }
     }
+    if (fence) {
+        HIP_TRY(hipEventRecord(fence->ev, s));
+        fence->pending = true;
+    }
+    return RND_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ one draw, nothing allocated */
+
+int rnd_draw_indexed_noalloc(rnd_device dev, const rnd_noalloc_draw* dr, rnd_fence fence)
+{
+    if (!dev || !dr || !dr->target || !dr->pipeline || !dr->vertex_buffer || !dr->index_buffer || !dr->uniform_block)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "draw_indexed_noalloc: bad arguments");
+    rnd_target tg = dr->target;
+    const rnd_pipeline_info& pi = dr->pipeline->info;
+    if (tg->dev != dev || dr->pipeline->dev != dev || dr->vertex_buffer->dev != dev || dr->index_buffer->dev != dev ||
+        (dr->texture && dr->texture->dev != dev))
+        return fail(RND_ERROR_INVALID_ARGUMENT, "draw_indexed_noalloc: an object belongs to another device");
+    if (!dev->scratch) return fail(RND_ERROR_INITIALIZATION_FAILED, "the static scratch array has no address on this device");
+    if (pi.samples != tg->samples) return fail(RND_ERROR_INVALID_ARGUMENT, "pipeline sample count differs from the target's");
+    const uint32_t tiles_x = (tg->width + TILE_W - 1) / TILE_W, tiles_y = (tg->height + TILE_H - 1) / TILE_H;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    const uint32_t tri_count = dr->index_count / 3;
+    if (n_tiles > NA_MAX_TILES)
+        return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "draw_indexed_noalloc: the target has " + std::to_string(n_tiles) + " tiles of 32x32 pixels, the static scratch array holds lists for " + std::to_string(NA_MAX_TILES));
+    if (dr->vertex_count > NA_MAX_VERTICES)
+        return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "draw_indexed_noalloc: " + std::to_string(dr->vertex_count) + " vertices, the static scratch array holds " + std::to_string(NA_MAX_VERTICES));
+    if (tri_count > NA_MAX_TRIANGLES)
+        return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "draw_indexed_noalloc: " + std::to_string(tri_count) + " triangles, the static scratch array holds " + std::to_string(NA_MAX_TRIANGLES));
+    if ((dr->vertex_offset_bytes & 3u) || dr->vertex_offset_bytes > dr->vertex_buffer->bytes ||
+        (dr->vertex_buffer->bytes - dr->vertex_offset_bytes) / pi.stride < dr->vertex_count)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "draw_indexed_noalloc: the vertices reach past the vertex buffer");
+    if ((dr->index_offset_bytes & 3u) || dr->index_offset_bytes > dr->index_buffer->bytes ||
+        (dr->index_buffer->bytes - dr->index_offset_bytes) / 4 < dr->index_count)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "draw_indexed_noalloc: the indices reach past the index buffer");
+    const float* vp = dr->viewport;
+    if (!(vp[2] > 0.0f) || !(vp[3] > 0.0f) || !(vp[4] >= 0.0f && vp[4] <= 1.0f) || !(vp[5] >= 0.0f && vp[5] <= 1.0f))
+        return fail(RND_ERROR_INVALID_ARGUMENT, "viewport extent or depth range invalid");
+    if (!(fabsf(vp[0] + 0.5f * vp[2]) + vp[2] + 1.0f < 32767.0f) || !(fabsf(vp[1] + 0.5f * vp[3]) + vp[3] + 1.0f < 32767.0f))
+        return fail(RND_ERROR_FEATURE_NOT_PRESENT, "viewport too large or too far from the origin");
+    if (dr->scissor[0] < 0 || dr->scissor[1] < 0 || dr->scissor[2] < 0 || dr->scissor[3] < 0)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "scissor offset and extent must be non-negative");
+    if (int r = set_device(dev)) return r;
+
+    uint8_t* base = dev->scratch;
+    DrawStatic d;
+    memset(&d, 0, sizeof(d));
+    d.vb = dr->vertex_buffer->ptr + dr->vertex_offset_bytes;
+    d.vb_capacity = dr->vertex_count;
+    d.ib = reinterpret_cast<const uint32_t*>(dr->index_buffer->ptr + dr->index_offset_bytes);
+    d.ubo = reinterpret_cast<const float*>(base + NoAllocLayout::ubo);
+    d.stride = pi.stride;
+    d.off_pos = (int32_t)pi.position.offset;
+    d.off_nrm = pi.normal.format ? (int32_t)pi.normal.offset : -1;
+    d.off_uv = pi.uv.format ? (int32_t)pi.uv.offset : -1;
+    d.tri_count = tri_count;
+    d.vert_count = tri_count ? dr->vertex_count : 0u;
+    d.shader = pi.shader;
+    d.texture = dr->texture ? 0 : -1;
+    d.cull_mode = (uint32_t)pi.cull_mode;
+    d.front_face = (uint32_t)pi.front_face;
+    if (dr->push_constants) memcpy(d.push, dr->push_constants, sizeof(d.push));
+
+    FrameParams fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.draws = reinterpret_cast<const DrawStatic*>(base + NoAllocLayout::draw);
+    fp.derived = reinterpret_cast<DrawDerived*>(base + NoAllocLayout::derived);
+    fp.counters = reinterpret_cast<uint32_t*>(base + NoAllocLayout::counters);
+    fp.tile_count = reinterpret_cast<uint32_t*>(base + NoAllocLayout::tile_count);
+    fp.svtx = reinterpret_cast<SVtx*>(base + NoAllocLayout::svtx);
+    fp.svary = reinterpret_cast<SVary*>(base + NoAllocLayout::svary);
+    fp.prim_rec = reinterpret_cast<PrimRec*>(base + NoAllocLayout::prim_rec);
+    fp.tile_lists = reinterpret_cast<TileEntry*>(base + NoAllocLayout::tile_lists);
+    fp.large_list = reinterpret_cast<LargeEntry*>(base + NoAllocLayout::large_list);
+    fp.clip_tris = reinterpret_cast<ClipTri*>(base + NoAllocLayout::clip_tris);
+    fp.tile_capacity = NA_TILE_CAPACITY; fp.tile_stride = NA_TILE_CAPACITY + 16;
+    fp.large_capacity = NA_LARGE_CAPACITY; fp.clip_tri_capacity = NA_CLIP_TRI_CAPACITY;
+    /* one draw: its chunks are its vertices and triangles in order, no chunk tables (vchunks / tchunks stay null) */
+    fp.n_draws = 1; fp.n_vchunks = (d.vert_count + CHUNK - 1) / CHUNK; fp.n_tchunks = (tri_count + CHUNK - 1) / CHUNK;
+    fp.direct_index = 1u;
+    const int depth_test = pi.depth_test ? 1 : 0, depth_less = (pi.depth_test && pi.depth_compare == RND_COMPARE_LESS) ? 1 : 0;
+    const int32_t area[4] = {0, 0, (int32_t)tg->width, (int32_t)tg->height};
+    pass_params(fp, dev, tg, area, true, vp, dr->scissor, dr->clear_color, dr->clear_depth, depth_test, depth_less);
+    if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
+    fp.pass_shader = d.shader;
+    fp.pass_texture = d.texture;
+    if (dr->texture) {
+        rnd_texture t = dr->texture;
+        for (uint32_t l = 0; l < t->levels; ++l) fp.pass_tex.level[l] = t->level_ptr[l];
+        fp.pass_tex.width = t->width; fp.pass_tex.height = t->height; fp.pass_tex.levels = t->levels;
+        fp.pass_tex.srgb = t->srgb; fp.pass_tex.tiled = t->sampler.tiled ? 1u : 0u;
+        fp.pass_tex.filter_linear = t->sampler.filtering == RND_FILTER_NEAREST ? 0u : 1u;
+    }
+    /* the uniform block travels in the vertex kernel's arguments, exactly like a small rnd_buffer_write */
+    UniformPatch patch;
+    patch.dst = base + NoAllocLayout::ubo;
+    patch.bytes = 320; patch.pad = 0;
+    memcpy(patch.words, dr->uniform_block, 320);
+
+    hipStream_t s = dev->stream;
+    HIP_TRY(follow_frames(dev));              /* frames of command buffers already submitted come first */
+    launch_noalloc_begin(d, base, n_tiles, s);
+    launch_vertex(fp, patch, s);
+    launch_setup(fp, s);
+    launch_tile(fp, s);
+    HIP_TRY(hipGetLastError());
+    ++dev->upload_seq;                        /* and later frames of command buffers follow this one */
+    tg->last_stream = s; tg->last_valid = true;
     if (fence) {
         HIP_TRY(hipEventRecord(fence->ev, s));
         fence->pending = true;

@@ -192,12 +192,12 @@ struct IndexRangeJob {
 /* phase stamps: thread 0 of every workgroup adds the cycles since its previous stamp to slot `i` of the workgroup's own row
  * (no atomics: a row has one writer) */
 #define RND_STAMP(fp, last, i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        if (threadIdx.x == 0u) { (fp).probe_cycles[(size_t)blockIdx.x * 16 + (i)] += now_ - (last); } (last) = now_; } while (0)
+        if (threadIdx.x == 0u && (fp).probe_cycles) { (fp).probe_cycles[(size_t)blockIdx.x * 16 + (i)] += now_ - (last); } (last) = now_; } while (0)
 #define RND_STAMP_START(last) unsigned long long last = __builtin_amdgcn_s_memtime(); \
-        if (threadIdx.x == 0u) { (fp).probe_cycles[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0u && (fp).probe_cycles) { (fp).probe_cycles[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); \
             (fp).probe_cycles[(size_t)blockIdx.x * 16 + 13] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | \
                                                               (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
-#define RND_STAMP_END(fp) do { if (threadIdx.x == 0u) (fp).probe_cycles[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RND_STAMP_END(fp) do { if (threadIdx.x == 0u && (fp).probe_cycles) (fp).probe_cycles[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RND_STAMP_END(fp) do { } while (0)
 #define RND_PROBE(fp, bit) false
@@ -256,6 +256,36 @@ struct FrameParams {
     uint32_t debug_flags;    /* probe masks of a build with RND_PROBES (timing experiments; results are wrong); otherwise unused */
 };
 
+
+/* rnd_draw_indexed_noalloc renders one draw with every intermediate buffer inside one static device array instead of
+ * allocations made at record time.  Its limits, and where each buffer lies in the array (offsets in bytes, all multiples
+ * of 256): */
+constexpr uint32_t NA_MAX_VERTICES = 65536;      /* vertices the draw may reference */
+constexpr uint32_t NA_MAX_TRIANGLES = 131072;
+constexpr uint32_t NA_MAX_TILES = 1024;          /* 32x32 tiles of the target: 1280x720 has 920 */
+constexpr uint32_t NA_TILE_CAPACITY = 1024;      /* entries per tile list before spilling to the pass-wide list */
+constexpr uint32_t NA_LARGE_CAPACITY = 32768;
+constexpr uint32_t NA_CLIP_TRI_CAPACITY = 16384;
+struct NoAllocLayout {
+    static constexpr size_t draw = 0;                                                     /* DrawStatic[1] */
+    static constexpr size_t derived = draw + 256;                                         /* DrawDerived[1] */
+    static constexpr size_t counters = derived + 256;                                     /* CTR_COUNT words */
+    static constexpr size_t ubo = counters + 256;                                         /* where the uniform block would live (320 bytes) */
+    static constexpr size_t tile_count = ubo + 512;
+    static constexpr size_t svtx = tile_count + (size_t)NA_MAX_TILES * TILE_COUNT_STRIDE * 4;
+    static constexpr size_t svary = svtx + (size_t)NA_MAX_VERTICES * sizeof(SVtx);
+    static constexpr size_t prim_rec = svary + (size_t)NA_MAX_VERTICES * sizeof(SVary);
+    static constexpr size_t tile_lists = prim_rec + (size_t)NA_MAX_TRIANGLES * sizeof(PrimRec);
+    static constexpr size_t large_list = tile_lists + (size_t)NA_MAX_TILES * (NA_TILE_CAPACITY + 16) * sizeof(TileEntry);
+    static constexpr size_t clip_tris = large_list + (size_t)NA_LARGE_CAPACITY * sizeof(LargeEntry);
+    static constexpr size_t total = clip_tris + (size_t)NA_CLIP_TRI_CAPACITY * sizeof(ClipTri);
+};
+static_assert(NoAllocLayout::total % 256 == 0 && NoAllocLayout::total < (size_t(32) << 20), "the static scratch array stays under 32 MiB");
+
+/* this device's address of the static scratch array (hipGetSymbolAddress; the current device's copy) */
+hipError_t noalloc_scratch_address(void** out);
+/* puts the draw's record into the array and zeroes what a frame expects to find at zero */
+void launch_noalloc_begin(const DrawStatic& d, uint8_t* scratch, uint32_t n_tiles, hipStream_t s);
 
 /* launch wrappers (rnd_kernels.hip) */
 void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n_jobs, hipStream_t s);

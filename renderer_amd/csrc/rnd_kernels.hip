@@ -21,7 +21,14 @@
  */
 #include "rnd_device.h"
 
+/* Scratch of rnd_draw_indexed_noalloc: every buffer a frame's kernels hand to one another (screen-space vertices, tile
+ * lists, counters, ...), laid out by rnd::NoAllocLayout.  In host code this name is only a handle for
+ * hipGetSymbolAddress; kernels get the address that call returns. */
+static __device__ __align__(256) unsigned char scratch[rnd::NoAllocLayout::total];
+
 namespace rnd {
+
+hipError_t noalloc_scratch_address(void** out) { return hipGetSymbolAddress(out, HIP_SYMBOL(scratch)); }
 
 /* ------------------------------------------------------------------ helpers */
 
@@ -547,7 +554,8 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
     __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_tchunks) return;
-    const Chunk c = fp.tchunks[chunk];
+    /* a pass without a chunk table is one draw whose chunks are its triangles in order */
+    const Chunk c = fp.tchunks ? fp.tchunks[chunk] : Chunk{0u, chunk * 64u};
     if (!fp.derived[c.draw].visible) return; /* the vertex kernel found the draw's box outside what this device renders */
     const DrawStatic& d = fp.draws[c.draw];
     const uint32_t lane = lane_id();
@@ -1815,6 +1823,26 @@ __global__ __launch_bounds__(256) void k_mip(const uint8_t* src, uint32_t sw, ui
         }
         reinterpret_cast<uint32_t*>(dst)[i] = out;
     }
+}
+
+/* ------------------------------------------------------------------ the pass that allocates nothing: set-up */
+
+/* One workgroup: the draw's record goes where the frame's kernels expect it, and the words a frame assumes to be zero
+ * at its start are zeroed (the array keeps whatever the previous call left). */
+__global__ __launch_bounds__(256) void k_noalloc_begin(DrawStatic d, uint8_t* base, uint32_t n_tiles)
+{
+    if (threadIdx.x == 0) *reinterpret_cast<DrawStatic*>(base + NoAllocLayout::draw) = d;
+    uint32_t* derived = reinterpret_cast<uint32_t*>(base + NoAllocLayout::derived);
+    if (threadIdx.x < sizeof(DrawDerived) / 4) derived[threadIdx.x] = 0u;
+    uint32_t* counters = reinterpret_cast<uint32_t*>(base + NoAllocLayout::counters);
+    if (threadIdx.x < CTR_COUNT) counters[threadIdx.x] = 0u;
+    uint32_t* tile_count = reinterpret_cast<uint32_t*>(base + NoAllocLayout::tile_count);
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += blockDim.x) tile_count[(size_t)t * TILE_COUNT_STRIDE] = 0u;
+}
+
+void launch_noalloc_begin(const DrawStatic& d, uint8_t* base, uint32_t n_tiles, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_noalloc_begin, dim3(1), dim3(256), 0, s, d, base, n_tiles);
 }
 
 /* ------------------------------------------------------------------ launch wrappers */
