@@ -110,12 +110,17 @@ struct SVtx {
     float iw;    /* 1/w */
 };
 
-/* Vertex-shader outputs besides the position: 32 bytes, two dwordx4 loads per corner in shading */
-struct __attribute__((aligned(32))) SVary {
+/* Vertex-shader outputs besides the position: 20 bytes, packed (a record starts on a 4-byte boundary); shading reads
+ * a corner's record as one 16-byte load and one word */
+struct SVary {
     float nx, ny, nz; /* v_normal (zero for the dummy shader, which does not light) */
     float u, v;       /* a_uv as stored */
+#ifdef RND_SVARY_PAD
     float pad[3];
+#endif
 };
+/* the first four words of a record as one load; the address is a multiple of 4, not of 16 */
+struct __attribute__((aligned(4))) SVaryHead { float x, y, z, w; };
 
 /* Per-draw record, immutable after recording */
 struct DrawStatic {

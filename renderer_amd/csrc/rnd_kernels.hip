@@ -348,7 +348,21 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     const uint32_t v = c.first + lane_id();
     const bool live = v < d.vert_count;
     float pos[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f}, uv[2] = {0.0f, 0.0f};
-    if (live) {
+    /* A record in the reference's full layout -- position, normal, uv interleaved, 32 bytes (obj_loader.cpp:98-109,
+     * 181-196) -- is fetched as two 16-byte loads, each of which uses half of every cache line it touches; any other
+     * layout word by word.  (The wave's 64 records fetched as 16-byte pieces in lane order and dealt to the lanes
+     * through LDS use whole lines per instruction, and were slower: the hop through LDS costs more than the second
+     * touch of each line, which the vector cache serves.) */
+    const bool full_layout = d.stride == 32u && d.off_pos == 0 && d.off_nrm == 12 && d.off_uv == 24;
+    if (live && full_layout) {
+        typedef float Half __attribute__((ext_vector_type(4), aligned(4)));
+        typedef const __attribute__((address_space(1))) Half* GlobalHalf;
+        const uint8_t* rec = d.vb + (size_t)v * 32u;
+        const Half a = *(GlobalHalf)rec, b = *(GlobalHalf)(rec + 16);
+        pos[0] = a.x; pos[1] = a.y; pos[2] = a.z;
+        nrm[0] = a.w; nrm[1] = b.x; nrm[2] = b.y;
+        uv[0] = b.z; uv[1] = b.w;
+    } else if (live) {
         const uint8_t* rec = d.vb + (size_t)v * d.stride;
         const float* p = reinterpret_cast<const float*>(rec + d.off_pos);
         pos[0] = load_f32(p); pos[1] = load_f32(p + 1); pos[2] = load_f32(p + 2);
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     fp.svtx[d.svtx_base + v] = out;
     /* the rest of the vertex shader: v_normal (test_ktx.vert:30, push_constants.vert:30) and v_uv */
     SVary vo;
-    vo.nx = vo.ny = vo.nz = 0.0f; vo.u = uv[0]; vo.v = uv[1]; vo.pad[0] = vo.pad[1] = vo.pad[2] = 0.0f;
+    vo.nx = vo.ny = vo.nz = 0.0f; vo.u = uv[0]; vo.v = uv[1];
     if (d.shader != 0) {
         const float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
         const float len = sqrtf(len2);
@@ -922,9 +936,8 @@ struct Varyings { float n[3]; float uv[2]; };
 /* Vertex-shader outputs other than the position, as the vertex kernel left them */
 __device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vtx, int shader, Varyings& out)
 {
-    const float4* rec = reinterpret_cast<const float4*>(&fp.svary[vtx]);
-    const float4 a = rec[0];
-    const float v = reinterpret_cast<const float*>(rec)[4];
+    const SVaryHead a = *reinterpret_cast<const SVaryHead*>(&fp.svary[vtx]);
+    const float v = fp.svary[vtx].v;
     out.n[0] = a.x; out.n[1] = a.y; out.n[2] = a.z;
     out.uv[0] = a.w;
     out.uv[1] = shader == 0 ? 1.0f - v : v; /* dummy.vert.glsl:25 flips v */
@@ -1604,9 +1617,8 @@ __device__ __forceinline__ void vc_fill(const FrameParams& fp, VtxCache& vc)
     for (uint32_t r = threadIdx.x; r < n; r += TILE_THREADS) {
         const uint32_t v = vc.recs[r * 2].x;
         const SVtx sv = fp.svtx[v];
-        const float4* rec = reinterpret_cast<const float4*>(&fp.svary[v]);
-        const float4 a = rec[0];
-        const float vv = reinterpret_cast<const float*>(rec)[4];
+        const SVaryHead a = *reinterpret_cast<const SVaryHead*>(&fp.svary[v]);
+        const float vv = fp.svary[v].v;
         vc.recs[r * 2] = make_uint4((uint32_t)sv.xf, (uint32_t)sv.y, __float_as_uint(sv.iw), __float_as_uint(a.w));
         vc.recs[r * 2 + 1] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(vv));
     }
