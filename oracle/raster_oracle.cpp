@@ -51,12 +51,13 @@ inline int32_t snap(float v)
     return (int32_t)t;
 }
 
-/* z in [0,1] -> D24: truncate(fma(z, 2^24-1, 0.5)), clamped */
+/* z in [0,1] -> D24: the float product z * (2^24 - 1) rounded to the nearest integer (ties to even).
+ * (Adding 0.5 and truncating is not that: from 2^23 on a float has no fraction bit left, the sum is itself
+ * rounded to an integer, and every value whose fraction is below one half comes out one too high.) */
 inline uint32_t depth24(float z)
 {
     z = fminf(fmaxf(z, 0.0f), 1.0f);
-    float t = fma32(z, 16777215.0f, 0.5f);
-    uint32_t d = (uint32_t)t;
+    uint32_t d = (uint32_t)rintf(z * 16777215.0f);
     return d > 0xFFFFFFu ? 0xFFFFFFu : d;
 }
 

@@ -384,8 +384,7 @@ uint32_t level_dim(uint32_t d, uint32_t l) { uint32_t v = d >> l; return v ? v :
 uint32_t host_depth24(float z)
 {
     z = fminf(fmaxf(z, 0.0f), 1.0f);
-    float t = fmaf(z, 16777215.0f, 0.5f);
-    uint32_t d = (uint32_t)t;
+    uint32_t d = (uint32_t)rintf(z * 16777215.0f); /* as the kernels convert: nearest integer, ties to even */
     return d > 0xFFFFFFu ? 0xFFFFFFu : d;
 }
 

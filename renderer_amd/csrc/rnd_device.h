@@ -52,12 +52,11 @@ __device__ __forceinline__ int32_t snap(float v)
     return (int32_t)t;
 }
 
-/* z -> D24: truncate(fma(clamp(z), 2^24-1, 0.5)) */
+/* z -> D24: the float product clamp(z) * (2^24 - 1) rounded to the nearest integer, ties to even (v_rndne_f32) */
 __device__ __forceinline__ uint32_t depth24(float z)
 {
     z = fminf(fmaxf(z, 0.0f), 1.0f);
-    float t = fma32(z, 16777215.0f, 0.5f);
-    uint32_t d = (uint32_t)t;
+    uint32_t d = (uint32_t)__builtin_rintf(z * 16777215.0f);
     return d > 0xFFFFFFu ? 0xFFFFFFu : d;
 }
 

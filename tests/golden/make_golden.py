@@ -37,6 +37,39 @@ def main():
         "snap": {repr(v): int(lib.orc_snap(v)) for v in [0.0, 0.001953125, 0.5, 1.0, 719.99609375, -0.75, 1919.5]},
         "log2_bits": {repr(v): int(np.float32(lib.orc_log2(v)).view(np.uint32)) for v in [0.3, 1.0, 1.5, 2.0, 7.25, 1000.0]},
     }
+    # sRGB encode: for every code k >= 1 the bits of the smallest float that encodes to it (floats of one sign order as
+    # their bit patterns, and the encoder is monotone: bisection over the bits)
+    first = []
+    for k in range(1, 256):
+        lo, hi = 0, 0x3F800000  # encode(bits lo) < k <= encode(bits hi)
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if lib.orc_srgb_encode(float(np.uint32(mid).view(np.float32))) >= k:
+                hi = mid
+            else:
+                lo = mid
+        first.append(hi)
+    kat["srgb_encode_first_bits"] = first
+    # texture(): sample points on small textures -- CLAMP_TO_EDGE and REPEAT outside [0, 1], a non-power-of-two size,
+    # footprints from magnified to beyond the last level ((uint32)log2(max(w, h)) levels, tools.cpp:514)
+    import ctypes as C
+    from renderer_amd import scenes
+    rng = np.random.RandomState(2024)
+    points = []
+    for (w, h, tiled, srgb) in [(64, 64, 0, 1), (64, 64, 1, 1), (40, 24, 0, 0), (17, 33, 1, 1)]:
+        levels = oracle.mip_chain(scenes.checker_texture(64, 3)[:h, :w].copy(), True, bool(srgb))
+        t = oracle.OrcTexture(w, h, len(levels), srgb, tiled, 1)
+        for i, l in enumerate(levels):
+            t.level_data[i] = l.ctypes.data_as(C.c_void_p).value
+        for k in range(8):
+            u, v = rng.uniform(-0.6, 1.6, 2)
+            foot = 2.0 ** (k * 1.5 - 3.0) / max(w, h)
+            args = np.array([u, v, foot, 0.3 * foot, -0.2 * foot, 0.8 * foot], dtype=np.float32)
+            out = (C.c_float * 4)()
+            lib.orc_sample_texture(C.byref(t), *[C.c_float(float(a)) for a in args], out)
+            points.append({"texture": [w, h, tiled, srgb], "levels": len(levels), "args_bits": [int(b) for b in args.view(np.uint32)],
+                           "rgba_bits": [int(b) for b in np.array(list(out), dtype=np.float32).view(np.uint32)]})
+    kat["sample_points"] = points
     mats = {}
     for (w, h) in [(800, 600), (1280, 720)]:
         cam = hm.Camera()

@@ -32,6 +32,28 @@ def test_known_answers(oracle):
         assert lib.orc_snap(float(v)) == s
     for v, b in kat["log2_bits"].items():
         assert int(np.float32(lib.orc_log2(float(v))).view(np.uint32)) == b
+    # sRGB encode table: code k starts at exactly the recorded float, and decode / encode round-trip
+    for k, bits in enumerate(kat["srgb_encode_first_bits"], start=1):
+        assert lib.orc_srgb_encode(float(np.uint32(bits).view(np.float32))) == k
+        assert lib.orc_srgb_encode(float(np.uint32(bits - 1).view(np.float32))) == k - 1
+        assert lib.orc_srgb_encode(lib.orc_srgb_decode(k)) == k
+    # texture() sample points
+    import ctypes as C
+    from renderer_amd import scenes
+    cache = {}
+    for pt in kat["sample_points"]:
+        w, h, tiled, srgb = pt["texture"]
+        if (w, h, srgb) not in cache:
+            cache[(w, h, srgb)] = oracle.mip_chain(scenes.checker_texture(64, 3)[:h, :w].copy(), True, bool(srgb))
+        levels = cache[(w, h, srgb)]
+        assert len(levels) == pt["levels"]
+        t = oracle.OrcTexture(w, h, len(levels), srgb, tiled, 1)
+        for i, l in enumerate(levels):
+            t.level_data[i] = l.ctypes.data_as(C.c_void_p).value
+        args = np.array(pt["args_bits"], dtype=np.uint32).view(np.float32)
+        out = (C.c_float * 4)()
+        lib.orc_sample_texture(C.byref(t), *[C.c_float(float(a)) for a in args], out)
+        assert [int(b) for b in np.array(list(out), dtype=np.float32).view(np.uint32)] == pt["rgba_bits"]
     mats = kat["matrices_float_bits"]
     for (w, h) in [(800, 600), (1280, 720)]:
         ubo = hm.global_ubo(hm.Camera(), hm.scale(hm.identity(), [0.12, 0.12, 0.12]), w, h)

@@ -1,0 +1,491 @@
+"""A second statement of the rules the oracle pins, in float64 numpy, compared with the oracle (CPU only).
+
+Written from the wording of the Vulkan 1.0 specification and the reference's shaders, NOT from
+oracle/raster_oracle.cpp, and in a different form wherever the rule allows one:
+
+* clipping and perspective-correct interpolation -- "Primitive Clipping" (0 <= z <= w) and "Polygons: basic
+  polygon rasterization" (f = sum(a_i f_i / w_i) / sum(a_i / w_i)) -- are evaluated per pixel in homogeneous
+  form: the weights l of pixel (px, py) over the three CLIP-space corners solve
+  [X0 X1 X2; Y0 Y1 Y2; w0 w1 w2] l = (px, py, 1) with X = w * window x.  No polygon is ever built, no fan,
+  no edge walk; the near and far planes are the sign of the interpolated z and w - z.
+* depth -- "Depth Test" / fixed-point conversion: round-to-nearest of z * (2^24 - 1);
+* texture() -- "Texel Filtering" and "Level-of-Detail Operation": rho from the scaled derivatives, lambda =
+  log2(rho) (exact log2), levels floor(lambda) and +1 blended by frac(lambda), texel (i, j) = floor(u * size - 0.5)
+  with its three neighbours, CLAMP_TO_EDGE or REPEAT; the reference's level count is (uint32)log2(max(w, h))
+  (tools.cpp:514), its sampler LINEAR/LINEAR/LINEAR (tools.cpp:60-82); mips by vkCmdBlitImage LINEAR (tools.cpp:651-708);
+* sRGB -- "sRGB EOTF" formulas as printed, then round(255 c).
+
+fp64 cannot decide a sample that lies within rounding distance of an edge, a clip plane, a depth tie or a
+rounding boundary; such samples are skipped AND COUNTED, and every test bounds how many it may skip.
+
+The reference holds no fixtures for this path (parity stays unpinned); this file is the most the repository can do
+from outside the oracle's own text.  A perturbed rule in the oracle (depth24 without its +0.5, snap without rounding,
+the perspective divide dropped, ...) fails the tests below.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import helpers
+from renderer_amd import hostmath as hm, scenes
+
+D24_MAX = float((1 << 24) - 1)
+EDGE_MARGIN_PX = 0.02      # fp64 coverage is not trusted closer than this to an edge or a clip plane
+DEPTH_TIE_UNITS = 6.0      # two fragments closer than this many D24 steps: the winner is not decided here
+
+
+# ------------------------------------------------------------------ sRGB, as printed in the specification
+
+def srgb_to_linear(c):
+    c = np.asarray(c, dtype=np.float64)
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def linear_to_srgb(c):
+    c = np.clip(np.asarray(c, dtype=np.float64), 0.0, 1.0)
+    return np.where(c <= 0.0031308, 12.92 * c, 1.055 * c ** (1.0 / 2.4) - 0.055)
+
+
+def encode_code_real(c, srgb):
+    """The real number whose rounding is the stored code."""
+    c = np.clip(np.asarray(c, dtype=np.float64), 0.0, 1.0)
+    return 255.0 * (linear_to_srgb(c) if srgb else c)
+
+
+# ------------------------------------------------------------------ texel filtering
+
+def decode_level(level, srgb):
+    t = level.astype(np.float64) / 255.0
+    if srgb:
+        t = np.concatenate([srgb_to_linear(t[..., :3]), t[..., 3:]], axis=-1)
+    return t
+
+
+def wrap(i, n, tiled):
+    return np.mod(i, n) if tiled else np.clip(i, 0, n - 1)
+
+
+def bilinear64(lv, u, v, tiled):
+    h, w = lv.shape[:2]
+    fu, fv = u * w - 0.5, v * h - 0.5
+    i, j = np.floor(fu), np.floor(fv)
+    a, b = fu - i, fv - j
+    i, j = i.astype(np.int64), j.astype(np.int64)
+    x0, x1, y0, y1 = wrap(i, w, tiled), wrap(i + 1, w, tiled), wrap(j, h, tiled), wrap(j + 1, h, tiled)
+    a, b = a[..., None], b[..., None]
+    return (1 - a) * (1 - b) * lv[y0, x0] + a * (1 - b) * lv[y0, x1] + (1 - a) * b * lv[y1, x0] + a * b * lv[y1, x1]
+
+
+def sample64(levels, tiled, u, v, dudx, dvdx, dudy, dvdy):
+    """texture() with a LINEAR / LINEAR / LINEAR sampler, lod in [0, levels - 1], no bias.
+    Returns (rgba, lambda)."""
+    h, w = levels[0].shape[:2]
+    rho_x = np.hypot(dudx * w, dvdx * h)
+    rho_y = np.hypot(dudy * w, dvdy * h)
+    rho = np.maximum(rho_x, rho_y)
+    with np.errstate(divide="ignore"):
+        lam = np.where(rho > 0, np.log2(np.maximum(rho, 1e-300)), -1000.0)
+    q = len(levels) - 1
+    lam = np.clip(lam, 0.0, float(q))
+    lo = np.floor(lam).astype(np.int64)
+    hi = np.minimum(lo + 1, q)
+    frac = lam - lo
+    out = np.zeros(u.shape + (4,), dtype=np.float64)
+    for l in range(q + 1):
+        m = lo == l
+        if m.any():
+            out[m] += (1.0 - frac[m])[..., None] * bilinear64(levels[l], u[m], v[m], tiled)
+        m = hi == l
+        if m.any():
+            out[m] += frac[m][..., None] * bilinear64(levels[l], u[m], v[m], tiled)
+    return out, lam
+
+
+def blit_linear64(src, srgb, dw, dh):
+    """vkCmdBlitImage with VK_FILTER_LINEAR from the whole source onto a dw x dh destination: destination texel
+    centre (x + .5, y + .5) maps to source coordinate (x + .5) * sw / dw, filtered as an unnormalised CLAMP_TO_EDGE
+    linear sample; sRGB formats are filtered in linear light.  Returns the real-valued codes before rounding."""
+    sh, sw = src.shape[:2]
+    lin = decode_level(src, srgb)
+    y, x = np.mgrid[0:dh, 0:dw]
+    u = (x + 0.5) * (sw / dw) / sw
+    v = (y + 0.5) * (sh / dh) / sh
+    t = bilinear64(lin, u, v, False)
+    if srgb:
+        return np.concatenate([255.0 * linear_to_srgb(t[..., :3]), 255.0 * t[..., 3:]], axis=-1)
+    return 255.0 * t
+
+
+# ------------------------------------------------------------------ the draw path per pixel, homogeneous form
+
+class Frame64:
+    def __init__(self, sc):
+        self.h, self.w = sc.height, sc.width
+        self.z = np.full((self.h, self.w), np.inf)       # window depth of the current winner
+        self.flat = np.zeros((self.h, self.w), dtype=bool)  # the winner's depth is the same constant at all corners
+        self.zgrad = np.zeros((self.h, self.w))          # |d zw / d pixel| of the winner
+        self.owner = np.full((self.h, self.w), -1, dtype=np.int64)
+        self.unsure = np.zeros((self.h, self.w), dtype=bool)
+        self.cleared_z = float(sc.clear_depth)
+
+
+def _mat(a):
+    return np.asarray(a, dtype=np.float64).reshape(4, 4).T  # stored column-major
+
+
+def render64(sc):
+    """Owner, depth and linear colour per pixel of a one-sample scene, with a mask of undecided pixels."""
+    assert sc.samples == 1
+    W, H = sc.width, sc.height
+    vx, vy, vw, vh, zmin, zmax = [float(t) for t in sc.viewport]
+    fr = Frame64(sc)
+    py, px = np.mgrid[0:H, 0:W]
+    pxc, pyc = px + 0.5, py + 0.5
+    prims = []  # per primitive: what shading needs
+    number = 0
+    for dr in sc.draws:
+        p = sc.pipelines[dr["pipeline"]]
+        ubo = np.asarray(sc.ubos[dr["ubo"]], dtype=np.float64)
+        model, mvp = _mat(ubo[48:64]), _mat(ubo[64:80])
+        push = np.asarray(dr["push"], dtype=np.float64)
+        color, transform = push[0:3], _mat(push[4:20])
+        shader = p["shader"]
+        clip_m = mvp if shader == scenes.SHADER_DUMMY else mvp @ transform
+        nrm_m = np.linalg.inv((model @ transform)[:3, :3]).T
+        vb = np.asarray(sc.vbs[dr["vb"]], dtype=np.float64).reshape(-1, 8)
+        ib = np.asarray(sc.ibs[dr["ib"]]).reshape(-1)[dr.get("first_index", 0):][:dr["index_count"]]
+        less = p["depth_compare"] == 1
+        for t in range(len(ib) // 3):
+            me = number
+            number += 1
+            corners = vb[ib[3 * t:3 * t + 3]]
+            c = (clip_m @ np.concatenate([corners[:, 0:3], np.ones((3, 1))], axis=1).T).T  # rows: x y z w
+            c[:, 1] = 1.0 - c[:, 1]  # test_ktx.vert:29, push_constants.vert:29, dummy.vert.glsl:23
+            if shader == scenes.SHADER_DUMMY:
+                nrm = corners[:, 3:6]
+                uv = np.stack([corners[:, 6], 1.0 - corners[:, 7]], axis=1)  # dummy.vert.glsl:25
+            else:
+                n_in = corners[:, 3:6] / np.linalg.norm(corners[:, 3:6], axis=1, keepdims=True)
+                nrm = (nrm_m @ n_in.T).T  # test_ktx.vert:30
+                uv = corners[:, 6:8]
+            prims.append(dict(c=c, nrm=nrm, uv=uv, shader=shader, color=color, texture=dr.get("texture", -1)))
+            if not np.isfinite(c).all():
+                continue
+            # homogeneous window coordinates: X = w * xw
+            A = np.stack([0.5 * vw * c[:, 0] + (vx + 0.5 * vw) * c[:, 3], 0.5 * vh * c[:, 1] + (vy + 0.5 * vh) * c[:, 3], c[:, 3]])
+            det = np.linalg.det(A)
+            scale = np.abs(A).max()
+            if abs(det) < 1e-12 * scale ** 3:
+                # degenerate on screen: the oracle may or may not see a sliver of it
+                continue
+            front = (-det > 0) if p["front_face"] == 0 else (-det < 0)
+            if (p["cull_mode"] & 2 and not front) or (p["cull_mode"] & 1 and front):
+                continue
+            Ai = np.linalg.inv(A)
+            prims[-1]["Ai"] = Ai
+            l = [Ai[k, 0] * pxc + Ai[k, 1] * pyc + Ai[k, 2] for k in range(3)]
+            grad = [math.hypot(Ai[k, 0], Ai[k, 1]) for k in range(3)]
+            zc = sum(l[k] * c[k, 2] for k in range(3))              # z / w_p  (times 1: l carries 1 / w_p)
+            wz = sum(l[k] * (c[k, 3] - c[k, 2]) for k in range(3))  # (w - z) / w_p
+            gz = math.hypot(sum(Ai[k, 0] * c[k, 2] for k in range(3)), sum(Ai[k, 1] * c[k, 2] for k in range(3)))
+            gwz = math.hypot(sum(Ai[k, 0] * (c[k, 3] - c[k, 2]) for k in range(3)), sum(Ai[k, 1] * (c[k, 3] - c[k, 2]) for k in range(3)))
+            funcs = [(l[0], grad[0]), (l[1], grad[1]), (l[2], grad[2]), (zc, gz), (wz, gwz)]
+            inside = np.ones((H, W), dtype=bool)
+            near_edge = np.zeros((H, W), dtype=bool)
+            for f, g in funcs:
+                d = f / g if g > 0 else np.where(f >= 0, np.inf, -np.inf)
+                inside &= d > 0
+                near_edge |= np.abs(d) < EDGE_MARGIN_PX
+            maybe = np.ones((H, W), dtype=bool)
+            for f, g in funcs:
+                d = f / g if g > 0 else np.where(f >= 0, np.inf, -np.inf)
+                maybe &= d > -EDGE_MARGIN_PX
+            sure = inside & ~near_edge
+            doubtful = maybe & ~sure
+            zw = zc * (zmax - zmin) + zmin   # z_clip / w_clip (the weights l carry 1 / w_clip), then the viewport's depth range
+            zw = np.clip(zw, 0.0, 1.0)
+            # window depth is affine in window space: its gradient from three of its values
+            with np.errstate(divide="ignore", invalid="ignore"):
+                def zw_at(x, y):
+                    ll = [Ai[k, 0] * x + Ai[k, 1] * y + Ai[k, 2] for k in range(3)]
+                    return sum(ll[k] * c[k, 2] for k in range(3)) * (zmax - zmin) + zmin
+                x_in, y_in = A[0].sum() / A[2].sum(), A[1].sum() / A[2].sum()  # the centroid's window position
+                zgrad = math.hypot(zw_at(x_in + 1, y_in) - zw_at(x_in, y_in), zw_at(x_in, y_in + 1) - zw_at(x_in, y_in))
+            if not np.isfinite(zgrad):
+                zgrad = 1.0
+            flat = bool(c[0, 2] * c[1, 3] == c[1, 2] * c[0, 3] and c[0, 2] * c[2, 3] == c[2, 2] * c[0, 3])
+            if not p["depth_test"]:
+                fr.unsure |= doubtful
+                fr.owner[sure] = me
+                continue
+            old = np.where(np.isinf(fr.z), fr.cleared_z, fr.z)
+            diff_units = (zw - old) * D24_MAX
+            exact_tie = flat & fr.flat & (zw == old) | (np.isinf(fr.z) & (zw == fr.cleared_z))
+            passes = np.where(exact_tie, not less, diff_units < 0)
+            # the vertices are snapped to 1/256 pixel before rasterisation: a depth moves by up to |grad| / 128
+            slack = DEPTH_TIE_UNITS + (zgrad + fr.zgrad) * (D24_MAX / 128.0)
+            close = (np.abs(diff_units) < slack) & ~exact_tie
+            fr.unsure |= sure & close
+            fr.unsure |= doubtful & (diff_units < slack)
+            take = sure & passes & (p["depth_write"] != 0)
+            fr.z[take] = zw[take]
+            fr.flat[take] = flat
+            fr.zgrad[take] = zgrad
+            fr.owner[take] = me
+    # shading of the winners
+    rgb = np.zeros((H, W, 3), dtype=np.float64)
+    lam_all = np.zeros((H, W), dtype=np.float64)
+    tex_levels = {}
+    for me in np.unique(fr.owner[fr.owner >= 0]):
+        pr = prims[me]
+        m = fr.owner == me
+        Ai = pr["Ai"]
+
+        def weights(x, y):
+            l = np.stack([Ai[k, 0] * x + Ai[k, 1] * y + Ai[k, 2] for k in range(3)], axis=-1)
+            return l / l.sum(axis=-1, keepdims=True)  # a_i / w_i over their sum: the perspective-correct weights
+
+        x, y = pxc[m], pyc[m]
+        mu = weights(x, y)
+        n = mu @ pr["nrm"]
+        light = np.array([0.0, 1.0, -1.0]) / math.sqrt(2.0)  # normalize(vec3(0, 1, -1)), test_ktx.frag:14
+        diff = np.maximum(n @ light, 0.0)
+        tex = np.ones((x.size, 3))
+        if pr["shader"] in (scenes.SHADER_DUMMY, scenes.SHADER_TEST_KTX):
+            ti = pr["texture"]
+            if ti is None or ti < 0:
+                tex = np.zeros((x.size, 3))
+            else:
+                if ti not in tex_levels:
+                    t = sc.textures[ti]
+                    tex_levels[ti] = ([decode_level(l, t.get("fmt", 43) in (15, 22, 29, 43, 50)) for l in t["_levels"]], bool(t.get("tiled", False)))
+                levels, tiled = tex_levels[ti]
+                uv = mu @ pr["uv"]
+                # derivatives by differencing inside the 2x2 quad (helper invocations extrapolate the same primitive)
+                odd_x, odd_y = (np.floor(x).astype(np.int64) & 1) == 1, (np.floor(y).astype(np.int64) & 1) == 1
+                uvx = weights(np.where(odd_x, x - 1, x + 1), y) @ pr["uv"]
+                uvy = weights(x, np.where(odd_y, y - 1, y + 1)) @ pr["uv"]
+                ddx = np.where(odd_x[:, None], uv - uvx, uvx - uv)
+                ddy = np.where(odd_y[:, None], uv - uvy, uvy - uv)
+                s, lam = sample64(levels, tiled, uv[:, 0], uv[:, 1], ddx[:, 0], ddx[:, 1], ddy[:, 0], ddy[:, 1])
+                tex = s[:, :3]
+                lam_all[m] = lam
+        if pr["shader"] == scenes.SHADER_DUMMY:
+            rgb[m] = tex
+        elif pr["shader"] == scenes.SHADER_TEST_KTX:
+            rgb[m] = tex * diff[:, None]
+        else:
+            rgb[m] = pr["color"][None, :] * diff[:, None]
+    return fr, rgb, lam_all
+
+
+def attach_levels(sc, oracle):
+    """Mip levels of the scene's textures (the blit rule has its own test; here they are data)."""
+    for t in sc.textures:
+        srgb = t.get("fmt", 43) in (15, 22, 29, 43, 50)
+        t["_levels"] = t["levels"] if t.get("levels") is not None else oracle.mip_chain(t["texels"], t.get("gen_mips", True), srgb)
+
+
+def compare(oracle, sc, stats, color_tol=1, check_lod_band=True):
+    attach_levels(sc, oracle)
+    color, depth, prim = oracle.render_scene(sc, want_prim=True)
+    fr, rgb, lam = render64(sc)
+    sure = ~fr.unsure
+    got_owner = prim[..., 0].astype(np.int64)
+    got_owner[got_owner == 0xFFFFFFFF] = -1
+    stats["pixels"] += int(sure.size)
+    stats["skipped"] += int((~sure).sum())
+    stats["covered"] += int((sure & (fr.owner >= 0)).sum())
+    # coverage and the depth test's winner, exactly
+    bad = sure & (got_owner != fr.owner)
+    assert not bad.any(), "owner differs at %s: oracle %s, fp64 %s" % (np.argwhere(bad)[:4].tolist(), got_owner[bad][:4], fr.owner[bad][:4])
+    # depth: the stored word against the real number it rounds
+    cov = sure & (fr.owner >= 0)
+    real = fr.z[cov] * D24_MAX
+    err = depth[..., 0][cov].astype(np.float64) - real
+    allow = 0.5 + 4.0 + fr.zgrad[cov] * (D24_MAX / 128.0)  # rounding, fp32 interpolation, the 1/256-pixel snap
+    assert (np.abs(err) <= allow).all(), "depth off by %s, allowed %s" % (np.abs(err)[np.abs(err) > allow][:4], allow[np.abs(err) > allow][:4])
+    stats["depth_err"].extend(err[fr.zgrad[cov] * (D24_MAX / 128.0) < 0.25].tolist())
+    assert (depth[..., 0][sure & (fr.owner < 0)] == int(math.floor(sc.clear_depth * D24_MAX + 0.5))).all()
+    # colour within one code
+    srgb_target = sc.color_format in (43, 50)
+    want_real = encode_code_real(rgb, srgb_target)
+    got = color[..., :3].astype(np.float64)
+    if sc.color_format in (44, 50):
+        got = got[..., ::-1]
+    cerr = np.abs(got - want_real)[cov]
+    stats["color_err"].extend(cerr.max(axis=-1).tolist() if cerr.size else [])
+    over = cerr.max(axis=-1) > 0.5 + color_tol if cerr.size else np.zeros(0, dtype=bool)
+    stats["color_over"] += int(over.sum())
+    assert (color[..., 3][cov] == 255).all()
+    return fr
+
+
+def new_stats():
+    return dict(pixels=0, skipped=0, covered=0, depth_err=[], color_err=[], color_over=0)
+
+
+def window_soup(W, H, n, seed, textured, w_range=(0.5, 4.0), flat_levels=0):
+    """Random triangles given in window space.  Without flat_levels every corner has a w of its own: the matrix
+    is a projection with clip w = object z and clip z = object z - 0.4, so depth = 1 - 0.4 / w."""
+    rng = np.random.RandomState(seed)
+    verts, idx = [], []
+    for t in range(n):
+        cx, cy = rng.uniform(-4, W + 4), rng.uniform(-4, H + 4)
+        ext = rng.uniform(1.5, 0.6 * W)
+        zt = rng.randint(0, flat_levels) / float(flat_levels) * 0.875 + 0.0625 if flat_levels else None
+        shallow = (t % 4) == 3  # some triangles nearly parallel to the screen: their depth words are decided by rounding alone
+        w0 = rng.uniform(*w_range)
+        for _k in range(3):
+            x, y = cx + rng.uniform(-1, 1) * ext, cy + rng.uniform(-1, 1) * ext
+            nrm = rng.normal(size=3) + np.array([0, 1.5, -1.5])
+            uv = [rng.uniform(-0.2, 1.2), rng.uniform(-0.2, 1.2)]
+            if flat_levels:
+                verts.append(helpers.window_to_position(x, y, zt, W, H, 1.0) + list(nrm) + uv)
+            else:
+                w = w0 * (1.0 + rng.uniform(-1e-6, 1e-6)) if shallow else rng.uniform(*w_range)
+                xd, yd = (x - W / 2.0) / (W / 2.0), (y - H / 2.0) / (H / 2.0)
+                verts.append([xd * w, 1.0 - yd * w, w] + list(nrm) + uv)
+            idx.append(len(idx))
+    kw = dict(pipeline_kw=dict(cull_mode=0))
+    if not flat_levels:
+        m = np.eye(4)
+        m[2, 3] = -0.4       # clip z = z - 0.4
+        m[3, 2], m[3, 3] = 1.0, 0.0  # clip w = z
+        ubo = helpers.identity_ubo()
+        ubo[64:80] = m.T.reshape(16).astype(np.float32)
+        kw["ubo"] = ubo
+    if textured:
+        tex = dict(texels=scenes.checker_texture(64, seed), gen_mips=True, filtering=1, tiled=bool(seed & 1), fmt=43)
+        return helpers.raw_scene(W, H, verts, idx, shader=scenes.SHADER_TEST_KTX, texture=tex, **kw)
+    return helpers.raw_scene(W, H, verts, idx, shader=scenes.SHADER_PUSH_CONSTANTS, color=(0.9, 0.6, 0.3, 1.0), **kw)
+
+
+# ------------------------------------------------------------------ tests
+
+def test_perspective_triangles_owner_depth_colour(oracle):
+    """240 triangles with per-corner w, untextured: owners exact, depth within fp32 of the fp64 value and centred on
+    it (round to nearest, not truncation), colour within one code."""
+    st = new_stats()
+    for seed in range(30):
+        compare(oracle, window_soup(48, 40, 8, 100 + seed, textured=False), st)
+    assert st["covered"] > 8000
+    assert st["skipped"] < 0.08 * st["pixels"]
+    # where the depth gradient is too small for the snap to matter, the stored word is within the float32 rounding of
+    # the corners' own depths (a step or two per corner, shared by all of a triangle's pixels) of the real value; the
+    # rounding rule itself is pinned exactly by the flat triangles of the next test
+    err = np.array(st["depth_err"])
+    assert err.size > 300 and np.abs(err).max() < 3.0, (err.size, np.abs(err).max())
+    assert st["color_over"] == 0, (st["color_over"], max(st["color_err"]))
+
+
+def test_flat_triangles_depth_words_exact_and_ties_by_submission_order(oracle):
+    """Triangles of constant depth k/32 with w = 1 (one of them 1/2, where z * (2^24 - 1) ends in .5): the depth word is floor(z * (2^24 - 1) + 1/2) exactly, and where two
+    of them tie the later one owns the pixel under LESS_OR_EQUAL, the earlier under LESS.  (An earlier version of the
+    oracle and of the kernels converted with truncate(fma(z, 2^24 - 1, 0.5)) in float32, which from depth 1/2 on -- no
+    fraction bit left -- returns one too many for every value whose fraction is below one half: 23/32 came out as
+    12058624 instead of 12058623.  This test found it.)"""
+    for compare_op in (3, 1):
+        st = new_stats()
+        for seed in range(10):
+            sc = window_soup(48, 40, 10, 300 + seed, textured=False, flat_levels=4)
+            sc.pipelines[0]["depth_compare"] = compare_op
+            fr = compare(oracle, sc, st)
+            _, depth, _ = oracle.render_scene(sc)
+            cov = ~fr.unsure & (fr.owner >= 0)
+            z = fr.z[cov]
+            exact = np.array([(int(round(v * 32)) * ((1 << 24) - 1) * 2 + 32) // 64 for v in z])  # z = k / 32
+            assert np.array_equal(depth[..., 0][cov], exact)
+        assert st["covered"] > 4000 and st["skipped"] < 0.08 * st["pixels"]
+        assert st["color_over"] == 0
+
+
+def test_textured_perspective_triangles(oracle):
+    """The same with the test_ktx shader: perspective-correct uv, quad derivatives, level of detail, trilinear
+    filtering, CLAMP_TO_EDGE and REPEAT (odd seeds), lighting, sRGB store."""
+    st = new_stats()
+    for seed in range(30):
+        compare(oracle, window_soup(48, 40, 8, 500 + seed, textured=True), st)
+    assert st["covered"] > 8000 and st["skipped"] < 0.08 * st["pixels"]
+    # one code everywhere but at a handful of pixels where a texel boundary or a level switch is closer than the
+    # 1/256-pixel snap of the vertices moves the sample
+    assert st["color_over"] <= 0.002 * st["covered"], (st["color_over"], st["covered"], max(st["color_err"]))
+    assert np.mean(np.array(st["color_err"]) <= 1.0) > 0.995
+
+
+def test_camera_soup_with_near_and_far_crossings(oracle):
+    """Triangles around the reference's camera (camera.cpp:9-25): many cross the near plane, w = 0 and the far plane.
+    The homogeneous statement never clips; the oracle clips, fans and rasterises the fan."""
+    st = new_stats()
+    crossing = 0
+    for seed in range(24):
+        sc = helpers.perspective_soup(48, 40, 10, 700 + seed, near_cross=True, pipeline_kw=dict(cull_mode=(0, 2)[seed & 1]))
+        vb = np.asarray(sc.vbs[0], dtype=np.float64).reshape(-1, 8)
+        c = (_mat(np.asarray(sc.ubos[0], dtype=np.float64)[64:80]) @ np.concatenate([vb[:, 0:3], np.ones((len(vb), 1))], axis=1).T).T
+        out = (c[:, 2] < 0) | (c[:, 2] > c[:, 3])
+        crossing += int(sum(0 < out[3 * t:3 * t + 3].sum() < 3 for t in range(len(vb) // 3)))
+        compare(oracle, sc, st)
+    assert crossing >= 40
+    assert st["covered"] > 4000 and st["skipped"] < 0.15 * st["pixels"]
+    assert st["color_over"] <= 0.002 * st["covered"], (st["color_over"], st["covered"])
+
+
+def test_sample_points(oracle):
+    """texture() at 400 points: both address modes, a non-power-of-two texture, footprints from magnified to the last level."""
+    lib = oracle.load()
+    rng = np.random.RandomState(9)
+    worst = 0.0
+    for (w, h, tiled, srgb) in [(64, 64, False, True), (64, 64, True, True), (40, 24, False, False), (17, 33, True, True)]:
+        texels = scenes.checker_texture(64, 3)[:h, :w].copy()
+        levels = oracle.mip_chain(texels, True, srgb)
+        assert len(levels) == int(math.log2(max(w, h)))  # tools.cpp:514: one short of a full chain
+        t = oracle.OrcTexture(w, h, len(levels), int(srgb), int(tiled), 1)
+        for i, l in enumerate(levels):
+            t.level_data[i] = l.ctypes.data_as(C.c_void_p).value
+        lin = [decode_level(l, srgb) for l in levels]
+        for _ in range(100):
+            u, v = rng.uniform(-0.6, 1.6, 2)
+            foot = 2.0 ** rng.uniform(-3, 7) / max(w, h)
+            ang = rng.uniform(0, 2 * np.pi, 2)
+            d = [foot * math.cos(ang[0]), foot * math.sin(ang[0]), 0.7 * foot * math.cos(ang[1]), 0.7 * foot * math.sin(ang[1])]
+            args = [float(np.float32(a)) for a in (u, v, d[0], d[1], d[2], d[3])]
+            out = (C.c_float * 4)()
+            lib.orc_sample_texture(C.byref(t), *[C.c_float(a) for a in args], out)
+            a64 = [np.array([a]) for a in args]
+            want, lam = sample64(lin, tiled, *a64)
+            # a level fraction off by the oracle's log2 polynomial (2e-5) times the difference between two levels
+            worst = max(worst, float(np.abs(np.array(out[:3]) - want[0, :3]).max()))
+    assert worst < 2e-5, worst
+
+
+def test_blit_rule_for_mips(oracle):
+    """Every mip level equals the LINEAR blit of the previous one within half a code plus float rounding, for
+    power-of-two and odd sizes, sRGB (filtered in linear light) and UNORM."""
+    for (w, h) in [(64, 64), (40, 24), (17, 33), (9, 2)]:
+        for srgb in (True, False):
+            texels = scenes.checker_texture(64, 5)[:h, :w].copy()
+            levels = oracle.mip_chain(texels, True, srgb)
+            assert len(levels) == max(int(math.log2(max(w, h))), 1)
+            for l in range(1, len(levels)):
+                dh, dw = levels[l].shape[:2]
+                assert (dw, dh) == (max(w >> l, 1), max(h >> l, 1))
+                real = blit_linear64(levels[l - 1], srgb, dw, dh)
+                assert np.abs(levels[l].astype(np.float64) - real).max() <= 0.5 + 2e-3
+
+
+def test_srgb_encode_against_the_printed_formula(oracle):
+    lib = oracle.load()
+    rng = np.random.RandomState(4)
+    vals = np.concatenate([rng.uniform(0, 1, 4000), rng.uniform(0, 0.01, 1000), [0.0, 1.0, 0.0031308, 0.5]]).astype(np.float32)
+    skipped = 0
+    for c in vals:
+        real = float(encode_code_real(float(c), True))
+        if abs(real - math.floor(real) - 0.5) < 2e-3:
+            skipped += 1
+            continue
+        assert lib.orc_srgb_encode(float(c)) == int(math.floor(real + 0.5))
+    assert skipped < 40
+    table = [lib.orc_srgb_decode(k) for k in range(256)]
+    assert np.abs(np.array(table) - srgb_to_linear(np.arange(256) / 255.0)).max() < 1e-7

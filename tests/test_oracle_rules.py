@@ -33,7 +33,9 @@ def test_depth24_known_answers(oracle):
     lib = oracle.load()
     assert lib.orc_depth24(0.0) == 0
     assert lib.orc_depth24(1.0) == 0xFFFFFF
-    assert lib.orc_depth24(0.5) == 8388608  # 8388607.5 + 0.5
+    assert lib.orc_depth24(0.5) == 8388608  # 8388607.5: the tie goes to the even neighbour
+    assert lib.orc_depth24(0.71875) == 12058623  # 12058623.28: down (adding 0.5 in float and truncating gives ...624)
+    assert lib.orc_depth24(0.75) == 12582911  # 12582911.25
     assert lib.orc_depth24(-3.0) == 0 and lib.orc_depth24(7.0) == 0xFFFFFF
     assert lib.orc_depth24(1.0 / 16777215.0) == 1
 
