@@ -212,7 +212,7 @@ struct rnd_cmd_t {
                 double sum[16] = {};
                 size_t rows = 0;
                 for (size_t r = 0; r < v.size() / 16; ++r) {
-                    if (!v[r * 16]) continue;
+                    if (!v[r * 16] || r >= fp.probe_kernel_row) continue;
                     ++rows;
                     for (int i = 0; i < 16; ++i) sum[i] += (double)v[r * 16 + i];
                 }
@@ -223,15 +223,23 @@ struct rnd_cmd_t {
                     unsigned long long t0 = ~0ull, t1 = 0; double life = 0;
                     std::vector<unsigned long long> starts;
                     for (size_t r = 0; r < v.size() / 16; ++r) {
-                        if (!v[r * 16]) continue;
+                        if (!v[r * 16] || r >= fp.probe_kernel_row) continue;
                         t0 = std::min(t0, v[r * 16 + 14]); t1 = std::max(t1, v[r * 16 + 15]);
                         life += (double)(v[r * 16 + 15] - v[r * 16 + 14]);
                         starts.push_back(v[r * 16 + 14]);
                     }
                     if (const char* dump = getenv("RND_PROBE_DUMP")) {
-                        if (FILE* f = fopen(dump, "w")) {
+                        /* appended: one block per command buffer, absolute 100 MHz ticks, so that the last frames of
+                         * command buffers in flight together can be laid side by side */
+                        if (FILE* f = fopen(dump, "a")) {
+                            const size_t kr = (size_t)fp.probe_kernel_row * 16;
+                            const size_t vb = (fp.n_vchunks + 3) / 4, sb = (fp.n_tchunks + 3) / 4;
+                            unsigned long long vend = 0, send = 0;
+                            for (size_t b = 0; b < vb && kr + 16 + b < v.size(); ++b) vend = std::max(vend, v[kr + 16 + b]);
+                            for (size_t b = 0; b < sb + 8 * 64 && kr + 16 + vb + b < v.size(); ++b) send = std::max(send, v[kr + 16 + vb + b]);
+                            fprintf(f, "# command buffer %p vertex %llu %llu setup %llu %llu\n", (void*)this, v[kr], vend, v[kr + 4], send);
                             for (size_t r = 0; r < v.size() / 16; ++r)
-                                if (v[r * 16]) fprintf(f, "%zu %llu %llu %llu %llu\n", r, v[r * 16 + 14] - t0, v[r * 16 + 15] - t0, v[r * 16 + 13] >> 32, v[r * 16 + 13] & 0xFFFFFFFFull);
+                                if (v[r * 16] && r < fp.probe_kernel_row) fprintf(f, "%zu %llu %llu %llu %llu\n", r, v[r * 16 + 14], v[r * 16 + 15], v[r * 16 + 13] >> 32, v[r * 16 + 13] & 0xFFFFFFFFull);
                             fclose(f);
                         }
                     }
@@ -1260,7 +1268,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     HIP_TRY(hipMemset(cmd->d_tile_count.ptr, 0, n_tiles * TILE_COUNT_STRIDE * sizeof(uint32_t)));
     HIP_TRY(hipMemset(cmd->d_counters.ptr, 0, CTR_COUNT * sizeof(uint32_t)));
 #ifdef RND_PROBES
-    HIP_TRY(cmd->d_probe.resize(((size_t)tiles_x * (tiles_y + 8) + 64) * 16)); /* the tile kernel's grid is padded to whole groups of eight rows */
+    HIP_TRY(cmd->d_probe.resize(((size_t)tiles_x * (tiles_y + 8) + 64) * 16 + vchunks.size() / 4 + tchunks.size() / 4 + 64 + 8 * 64)); /* the tile kernel's grid is padded to whole groups of eight rows */
     HIP_TRY(hipMemset(cmd->d_probe.ptr, 0, cmd->d_probe.count * sizeof(unsigned long long)));
 #endif
 
@@ -1273,6 +1281,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     fp.large_list = cmd->d_large_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
     fp.counters = cmd->d_counters.ptr;
     fp.probe_cycles = cmd->d_probe.ptr;
+    fp.probe_kernel_row = tiles_x * (tiles_y + 8) + 8;
     fp.tile_capacity = (uint32_t)tile_cap; fp.tile_stride = (uint32_t)tile_stride; fp.large_capacity = (uint32_t)large_cap;
     fp.clip_tri_capacity = (uint32_t)clip_tri_cap;
     fp.n_draws = (uint32_t)n; fp.n_vchunks = (uint32_t)vchunks.size(); fp.n_tchunks = (uint32_t)tchunks.size();

@@ -203,7 +203,15 @@ struct IndexRangeJob {
             (fp).probe_cycles[(size_t)blockIdx.x * 16 + 13] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | \
                                                               (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
 #define RND_STAMP_END(fp) do { if (threadIdx.x == 0u && (fp).probe_cycles) (fp).probe_cycles[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } while (0)
+/* when a whole kernel ran (100 MHz ticks): workgroup 0 leaves its start in word 4 * k of the row after the tile kernel's rows,
+ * every workgroup its end in a word of its own (no atomics: they would serialise the kernel being timed) from `first` on */
+#define RND_KERNEL_BEGIN(fp, k) do { if ((fp).probe_cycles && blockIdx.x == 0u && threadIdx.x == 0u) \
+        (fp).probe_cycles[(size_t)(fp).probe_kernel_row * 16 + 4 * (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RND_KERNEL_END(fp, first) do { if ((fp).probe_cycles && threadIdx.x == 0u) \
+        (fp).probe_cycles[(size_t)(fp).probe_kernel_row * 16 + 16 + (first) + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define RND_KERNEL_BEGIN(fp, k) do { } while (0)
+#define RND_KERNEL_END(fp, k) do { } while (0)
 #define RND_STAMP_END(fp) do { } while (0)
 #define RND_PROBE(fp, bit) false
 #define RND_STAMP(fp, last, i) do { } while (0)
@@ -258,6 +266,7 @@ struct FrameParams {
     uint32_t vtx_cache;      /* 1: the tile kernel stages the corners its visible primitives use in LDS (one sample per pixel,
                                 vertex numbers below VC_MAX_VERTEX) */
     unsigned long long* probe_cycles; /* a build with RND_PROBES: wave-cycles summed per phase of the tile kernel; otherwise null */
+    uint32_t probe_kernel_row; /* a build with RND_PROBES: the row of probe_cycles that holds whole-kernel start and end times */
     uint32_t debug_flags;    /* probe masks of a build with RND_PROBES (timing experiments; results are wrong); otherwise unused */
 };
 

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 {
     const FrameParams& fp = args.fp;
     const UniformPatch& up = args.up;
+    RND_KERNEL_BEGIN(fp, 0);
     /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel */
     if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
         vo.nx = tn[0]; vo.ny = tn[1]; vo.nz = tn[2];
     }
     fp.svary[d.svtx_base + v] = vo;
+    RND_KERNEL_END(fp, 0u);
 }
 
 /* ------------------------------------------------------------------ setup: cull, orient, bin (one pass) */
@@ -566,6 +568,7 @@ __device__ __forceinline__ void clip_primitive(const FrameParams& fp, const Draw
 __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
 {
     __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
+    RND_KERNEL_BEGIN(fp, 1);
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_tchunks) return;
     /* a pass without a chunk table is one draw whose chunks are its triangles in order */
@@ -607,6 +610,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
 
     /* Primitives that cross the near plane, the far plane or the guard band (rare): the wave clips
      * them CLIP_LANES at a time, lane j taking the j-th of them, with the polygons in LDS. */
+    RND_KERNEL_END(fp, (fp.n_vchunks + 3u) / 4u);
     uint64_t cm = __ballot(needs_clip);
     if (!cm) return;
     ClipStore st;

@@ -54,13 +54,21 @@ def main(src, dst_prefix, config=None):
         for n in names:
             w.writerow([n] + [rows[n].get(c, "") for c in cols])
     # HBM traffic per launch for the benchmark's roofline line.  FETCH_SIZE / WRITE_SIZE are in KiB;
-    # on gfx950 FETCH_SIZE counts 128-byte read requests as 64 bytes, so reads are doubled.
+    # on gfx950 FETCH_SIZE counts every read request as 64 bytes while the requests are 128-byte ones, for wide
+    # streaming reads and for isolated 4-byte gathers alike (tools/micro/fetch_calib.hip, profiles/r02_fetch_calib.json),
+    # so reads are doubled.  When the pass with the size-resolved request counters was collected, the read bytes are
+    # taken from it instead (32 / 64 / 128 bytes per request of each size: no correction needed).
     traffic = {}
     for n, r in rows.items():
         if "FETCH_SIZE" in r and "WRITE_SIZE" in r:
             short = n.split("(")[0].replace("void ", "").replace("rnd::", "")
-            traffic[short] = {"read_bytes": 2.0 * r["FETCH_SIZE"] * 1024.0, "write_bytes": r["WRITE_SIZE"] * 1024.0,
-                              "avg_us": r.get("avg_us"), "valu_insts": r.get("SQ_INSTS_VALU")}
+            read = 2.0 * r["FETCH_SIZE"] * 1024.0
+            source = "FETCH_SIZE x 2"
+            if "TCC_EA0_RDREQ_128B_sum" in r:
+                read = 32.0 * r.get("TCC_EA0_RDREQ_32B_sum", 0.0) + 64.0 * r.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 128.0 * r["TCC_EA0_RDREQ_128B_sum"]
+                source = "TCC_EA0_RDREQ by request size"
+            traffic[short] = {"read_bytes": read, "read_bytes_source": source, "read_bytes_fetch_size_x2": 2.0 * r["FETCH_SIZE"] * 1024.0,
+                              "write_bytes": r["WRITE_SIZE"] * 1024.0, "avg_us": r.get("avg_us"), "valu_insts": r.get("SQ_INSTS_VALU")}
     with open(dst_prefix + "_traffic.json", "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     print("wrote", dst_prefix + "_pmc.csv", dst_prefix + "_traffic.json")
