@@ -26,6 +26,28 @@ def test_header_symbols_are_exported():
     assert sorted(_lib.SYMBOLS) == names
 
 
+def test_vulkan_named_entry_points_are_exported():
+    """include/rnd_vk.h: every vk*, vma* and rndVk* function it declares is exported by librnd_vk.so, which loads without
+    a GPU (its structure sizes are checked against the Vulkan ABI at compile time, renderer_amd/csrc/rnd_vk.cpp)."""
+    text = open(os.path.join(ROOT, "include", "rnd_vk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b((?:vk|vma|rndVk)[A-Z][A-Za-z0-9]+)\s*\(", text)))
+    assert len(names) >= 50 and "vkCmdDrawIndexed" in names and "vkQueueSubmit" in names and "vmaFlushAllocation" in names
+    lib = ctypes.CDLL(os.path.join(ROOT, "renderer_amd", "librnd_vk.so"))
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    lib.rndVkCreateDevice.restype = ctypes.c_int
+    dev = ctypes.c_void_p()
+    if not _has_gpu():
+        assert lib.rndVkCreateDevice(0, ctypes.byref(dev), None, None) == -3  # VK_ERROR_INITIALIZATION_FAILED
+        lib.rndVkLastError.restype = ctypes.c_char_p
+        assert b"HIP device" in lib.rndVkLastError()
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
 def test_binding_loads_and_types_are_declared():
     lib = _lib.load()
     for n in _lib.SYMBOLS:

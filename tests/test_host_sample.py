@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAMPLE = os.path.join(ROOT, "samples", "test_ktx_app_headless")
 SAMPLE_NOEXC = os.path.join(ROOT, "samples", "test_ktx_app_headless_noexcept")
 SAMPLE_PUSH = os.path.join(ROOT, "samples", "test_push_constants_app_headless")
+SAMPLE_VK = os.path.join(ROOT, "samples", "test_ktx_app_vk_headless")  # the same sample through the reference's own Vulkan names (include/rnd_vk.h)
 
 
 def dump_ubo(w, h):
@@ -45,11 +46,11 @@ def _has_gpu():
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure path")
-@pytest.mark.parametrize("exe", [SAMPLE, SAMPLE_NOEXC])
+@pytest.mark.parametrize("exe", [SAMPLE, SAMPLE_NOEXC, SAMPLE_VK])
 def test_sample_fails_loudly_without_gpu(exe):
     r = subprocess.run([exe, "--frames", "1"], capture_output=True, text=True)
     assert r.returncode == 1
-    assert "no HIP device is visible" in r.stderr and "rnd_device_create" in r.stderr
+    assert "no HIP device is visible" in r.stderr and ("rnd_device_create" in r.stderr or "context::init" in r.stderr)
 
 
 def fnv1a(data):
@@ -71,7 +72,7 @@ def cpp_checker(size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exe", [SAMPLE, SAMPLE_NOEXC, SAMPLE_PUSH])
+@pytest.mark.parametrize("exe", [SAMPLE, SAMPLE_NOEXC, SAMPLE_PUSH, SAMPLE_VK])
 def test_sample_frame_matches_oracle(oracle, exe):
     w, h = 320, 180
     out = subprocess.run([exe, "--frames", "1", "--width", str(w), "--height", str(h)], check=True,
