@@ -11,8 +11,11 @@
 namespace rnd {
 
 constexpr int TILE_W = 32;           /* pixels per tile side: one workgroup owns a tile's depth/owner words in LDS */
-constexpr int TILE_H = 32;
-constexpr int TILE_SHIFT = 5;
+#ifndef TILE_H_PX
+#define TILE_H_PX 32
+#endif
+constexpr int TILE_H = TILE_H_PX;    /* a multiple of 8: every thread of a tile's workgroup shades TILE_H / 8 pixels */
+constexpr int TILE_SHIFT = 5;        /* log2(TILE_W) */
 constexpr int TILE_PIXELS = TILE_W * TILE_H;
 constexpr int TILE_THREADS = 256;
 constexpr int CHUNK = 64;            /* primitives (or vertices) handled by one wave */

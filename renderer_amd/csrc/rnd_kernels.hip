@@ -558,7 +558,7 @@ __device__ __forceinline__ void clip_primitive(const FrameParams& fp, const Draw
         fp.clip_tris[idx] = ct;
         if (vis) {
             TileEntry e = {idx, 0u, 0u, slot | ((uint32_t)(k - 1) << ENTRY_SUB_SHIFT) | FLAG_CLIPPED};
-            bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, y0 >> TILE_SHIFT, x1 >> TILE_SHIFT, y1 >> TILE_SHIFT));
+            bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, y0 / TILE_H, x1 >> TILE_SHIFT, y1 / TILE_H));
         }
     }
 }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
             int x0, y0, x1, y1;
             if (setup_tri(t, d.cull_mode, d.front_face) && pixel_box(fp, t, x0, y0, x1, y1)) {
                 valid = true;
-                box = pack_bbox(x0 >> TILE_SHIFT, y0 >> TILE_SHIFT, x1 >> TILE_SHIFT, y1 >> TILE_SHIFT);
+                box = pack_bbox(x0 >> TILE_SHIFT, y0 / TILE_H, x1 >> TILE_SHIFT, y1 / TILE_H);
                 const uint32_t v0 = d.svtx_base + pf.idx[0], v1 = d.svtx_base + pf.idx[1], v2 = d.svtx_base + pf.idx[2];
                 /* what shading needs, in the primitive's own corner order */
                 PrimRec pr = {v0, v1, v2, c.draw};

@@ -9,7 +9,9 @@ if len(sys.argv) > 1 and sys.argv[1] != "--child":
         os.remove(dump)
     env = dict(os.environ, RND_PROBE_DUMP=dump)
     subprocess.run([sys.executable, __file__, "--child"] + sys.argv[1:], env=env, check=True)
-    subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "probe_overlap.py"), dump], check=True)
+    import bench
+    cols = (bench.build_scene(int(sys.argv[1])).width + 31) // 32  # tile columns: workgroup number -> tile
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "probe_overlap.py"), dump, str(cols)], check=True)
     sys.exit(0)
 import bench
 from renderer_amd.runner import SceneRunner
