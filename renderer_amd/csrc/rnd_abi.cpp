@@ -1292,12 +1292,6 @@ int rnd_cmd_end(rnd_cmd cmd)
      * still clears the render area) */
     if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
     fp.direct_index = n == 1 ? 1u : 0u;
-    {
-        /* RND_VTX_CACHE=0 in the environment switches the tile kernel's LDS vertex cache off when a command buffer is
-         * recorded (for timing one path against the other, and so that tests reach the path without it) */
-        const char* sw = getenv("RND_VTX_CACHE");
-        fp.vtx_cache = (tg->samples == 1 && svtx_total <= VC_MAX_VERTEX && !(sw && sw[0] == '0')) ? 1u : 0u;
-    }
     fp.pass_shader = n ? ds[0].shader : -1;
     fp.pass_texture = n ? ds[0].texture : -1;
     for (size_t i = 1; i < n; ++i) {

@@ -50,20 +50,6 @@ struct __attribute__((aligned(16))) ShadeTables {
     uint8_t pad[12]; /* size is a multiple of 16 bytes */
 };
 
-/* The tile kernel's per-tile vertex cache (LDS): after rasterisation the corners of the tile's visible primitives are
- * entered into a hash set of VC_TAGS words, each distinct vertex gets one of VC_RECS 32-byte records, filled once from
- * device memory, and shading reads its corners from there.  A tag word is vertex << VC_IDX_BITS | record. */
-constexpr uint32_t VC_TAGS = 1024;
-#ifndef VC_RECS
-#define VC_RECS 480
-#endif
-constexpr uint32_t VC_IDX_BITS = 9;
-constexpr uint32_t VC_IDX_NONE = (1u << VC_IDX_BITS) - 1u;       /* no record (yet, or none left) */
-constexpr uint32_t VC_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t VC_MAX_VERTEX = (1u << (32 - VC_IDX_BITS)) - 1u; /* vertex numbers a tag can hold without colliding with VC_EMPTY */
-constexpr int VC_PROBES = 8;
-static_assert(VC_RECS <= VC_IDX_NONE, "record numbers must fit the tag's low bits");
-
 /* Bits of TileEntry::slot_flags and PrimRec::draw_flags */
 constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   /* primitive slot (submission number) */
 constexpr uint32_t ENTRY_SUB_SHIFT = 28;      /* bits 28..30: fan index of a clipped primitive's triangle */
@@ -266,8 +252,6 @@ struct FrameParams {
     int32_t pass_shader;     /* shader of every draw of the pass, or -1 when they differ */
     int32_t pass_texture;    /* texture index of every draw (-1: none bound), or -2 when they differ */
     TexDesc pass_tex;        /* textures[pass_texture] by value */
-    uint32_t vtx_cache;      /* 1: the tile kernel stages the corners its visible primitives use in LDS (one sample per pixel,
-                                vertex numbers below VC_MAX_VERTEX) */
     unsigned long long* probe_cycles; /* a build with RND_PROBES: wave-cycles summed per phase of the tile kernel; otherwise null */
     uint32_t probe_kernel_row; /* a build with RND_PROBES: the row of probe_cycles that holds whole-kernel start and end times */
     uint32_t debug_flags;    /* probe masks of a build with RND_PROBES (timing experiments; results are wrong); otherwise unused */

@@ -1316,6 +1316,7 @@ __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Shad
             float u = interp(lam, v0.uv[0], v1.uv[0], v2.uv[0]), v = interp(lam, v0.uv[1], v1.uv[1], v2.uv[1]);
             float unx = interp(lnx, v0.uv[0], v1.uv[0], v2.uv[0]), vnx = interp(lnx, v0.uv[1], v1.uv[1], v2.uv[1]);
             float uny = interp(lny, v0.uv[0], v1.uv[0], v2.uv[0]), vny = interp(lny, v0.uv[1], v1.uv[1], v2.uv[1]);
+            if (RND_PROBE(fp, 512u)) { u = 0.5f; v = 0.5f; unx = 0.5001f; vnx = 0.5f; uny = 0.5f; vny = 0.5001f; } /* every lane samples the same texels */
             float dudx = (x & 1) ? u - unx : unx - u, dvdx = (x & 1) ? v - vnx : vnx - v;
             float dudy = (y & 1) ? u - uny : uny - u, dvdy = (y & 1) ? v - vny : vny - v;
             if (fp.pass_texture >= 0) sample_texture<true>(tb, fp.pass_tex, pass_levels, u, v, dudx, dvdx, dudy, dvdy, tex);
@@ -1364,6 +1365,7 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
         pr = fp.prim_rec[slot];
     }
     uint32_t vtx[3] = {pr.v0, pr.v1, pr.v2};
+    if (RND_PROBE(fp, 256u)) { vtx[0] = 0u; vtx[1] = 1u; vtx[2] = 2u; } /* every lane gathers the same three vertices: what the gathers' spread costs */
     uint32_t draw = pr.draw_flags & SLOT_MASK;
     if (clipped) {
         const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
@@ -1508,182 +1510,6 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
     reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, acc);
 }
 
-/* ---- per-tile vertex cache ---- */
-
-struct VtxCache {
-    uint32_t tags[VC_TAGS];     /* hash set of vertex numbers: vertex << VC_IDX_BITS | record, or VC_EMPTY */
-    uint4 recs[VC_RECS * 2];    /* record r: {x24.8 << 8 | outcode, y24.8, 1/w, u} {nx, ny, nz, v}; word 0 holds the vertex number until the record is filled */
-    uint32_t count;             /* records handed out (may run past VC_RECS: the surplus vertices stay uncached) */
-    uint32_t pad[3];
-};
-
-constexpr uint32_t VC_POS_BITS = 10;
-constexpr uint32_t VC_PIXEL_UNCACHED = 1u << 31; /* in a pixel's packed hash positions: some corner has no record */
-static_assert((1u << VC_POS_BITS) == VC_TAGS, "a hash position is VC_POS_BITS wide");
-
-/* Enters vertex v into the set (lanes with want == false only take part in the wave-wide steps).  Returns the
- * position of its tag word, or VC_TAGS when VC_PROBES positions were all taken by other vertices.  The lane that
- * claims an empty position hands the vertex a record number (one LDS add per wave and round: ballot + popcount) and
- * leaves the vertex number in the record for the fill. */
-__device__ __forceinline__ uint32_t vc_insert(VtxCache& vc, uint32_t v, bool want)
-{
-    uint32_t h = (v * 0x9E3779B1u) >> (32 - VC_POS_BITS);
-    uint32_t pos = VC_TAGS;
-    bool pending = want;
-    const uint32_t lane = lane_id();
-#pragma unroll 1
-    for (int probe = 0; probe < VC_PROBES; ++probe) {
-        if (!__ballot(pending)) break;
-        uint32_t old = 0u;
-        if (pending) old = atomicCAS(&vc.tags[h], VC_EMPTY, (v << VC_IDX_BITS) | VC_IDX_NONE);
-        const bool won = pending && old == VC_EMPTY;
-        const bool same = pending && old != VC_EMPTY && (old >> VC_IDX_BITS) == v;
-        const uint64_t winners = __ballot(won);
-        if (winners) {
-            const int leader = __ffsll((unsigned long long)winners) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&vc.count, (uint32_t)__popcll(winners));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (won) {
-                const uint32_t rec = base + (uint32_t)__popcll(winners & ((1ull << lane) - 1ull));
-                if (rec < VC_RECS) {
-                    vc.tags[h] = (v << VC_IDX_BITS) | rec;
-                    vc.recs[rec * 2].x = v;
-                }
-            }
-        }
-        if (won || same) { pos = h; pending = false; }
-        else if (pending) h = (h + 1u) & (VC_TAGS - 1u);
-    }
-    return pos;
-}
-
-/* After rasterisation: every thread takes four of the tile's pixels, stores their depth words, finds the three
- * corners of each pixel's owner (index buffer or primitive record: one load per pixel, the four in flight together)
- * and enters them into the set.  The pixel's word in `keys` then becomes owner | packed hash positions << 32. */
-__device__ __forceinline__ void vc_collect(const FrameParams& fp, const TileCtx& tc, VtxCache& vc, unsigned long long clear_key)
-{
-    uint32_t vis[4], vtx[4][3];
-    bool use[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t p = threadIdx.x + (uint32_t)j * TILE_THREADS;
-        const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
-        const bool inside = x >= fp.area_x0 && x <= fp.area_x1 && y >= fp.area_y0 && y <= fp.area_y1;
-        const unsigned long long k = tc.keys[p];
-        vis[j] = VIS_NONE;
-        if (inside) {
-            fp.depth[(size_t)y * fp.width + (size_t)x] = fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24;
-            if (k != clear_key) {
-                const uint32_t low = (uint32_t)(k >> 8);
-                vis[j] = ((fp.depth_less ? low : ~low) & SLOT_MASK) | ((uint32_t)(k & 15ull) << ENTRY_SUB_SHIFT);
-            }
-        }
-        /* a clipped primitive's corners live in its fan triangles' records: such pixels take the uncached path */
-        use[j] = vis[j] != VIS_NONE && !(vis[j] & FLAG_CLIPPED);
-        vtx[j][0] = vtx[j][1] = vtx[j][2] = 0u;
-    }
-    if (fp.direct_index) {
-        const DrawStatic& d = fp.draws[0];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!use[j]) continue;
-            const uint32_t* ip = d.ib + (size_t)(vis[j] & SLOT_MASK) * 3;
-            vtx[j][0] = d.svtx_base + load_u32(ip); vtx[j][1] = d.svtx_base + load_u32(ip + 1); vtx[j][2] = d.svtx_base + load_u32(ip + 2);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!use[j]) continue;
-            const PrimRec pr = fp.prim_rec[vis[j] & SLOT_MASK];
-            vtx[j][0] = pr.v0; vtx[j][1] = pr.v1; vtx[j][2] = pr.v2;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t packed = 0u;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t pos = vc_insert(vc, vtx[j][c], use[j]);
-            if (pos >= VC_TAGS) packed |= VC_PIXEL_UNCACHED;
-            packed |= (pos & (VC_TAGS - 1u)) << (VC_POS_BITS * c);
-        }
-        if (!use[j]) packed = VC_PIXEL_UNCACHED;
-        tc.keys[threadIdx.x + (uint32_t)j * TILE_THREADS] = ((unsigned long long)packed << 32) | vis[j];
-    }
-}
-
-/* Every record handed out is filled once, one thread per vertex: the screen-space vertex and the vertex shader's
- * other outputs, 36 bytes from device memory into 32 bytes of LDS (depth is not needed for shading). */
-__device__ __forceinline__ void vc_fill(const FrameParams& fp, VtxCache& vc)
-{
-    const uint32_t n = min(vc.count, (uint32_t)VC_RECS);
-    for (uint32_t r = threadIdx.x; r < n; r += TILE_THREADS) {
-        const uint32_t v = vc.recs[r * 2].x;
-        const SVtx sv = fp.svtx[v];
-        const SVaryHead a = *reinterpret_cast<const SVaryHead*>(&fp.svary[v]);
-        const float vv = fp.svary[v].v;
-        vc.recs[r * 2] = make_uint4((uint32_t)sv.xf, (uint32_t)sv.y, __float_as_uint(sv.iw), __float_as_uint(a.w));
-        vc.recs[r * 2 + 1] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(vv));
-    }
-}
-
-__device__ __forceinline__ void vc_corner(const VtxCache& vc, uint32_t rec, int shader, int k, Corners& c, Varyings& out)
-{
-    const uint4 a = vc.recs[rec * 2], b = vc.recs[rec * 2 + 1];
-    c.x[k] = (int32_t)a.x >> 8; c.y[k] = (int32_t)a.y; c.iw[k] = __uint_as_float(a.z);
-    out.n[0] = __uint_as_float(b.x); out.n[1] = __uint_as_float(b.y); out.n[2] = __uint_as_float(b.z);
-    out.uv[0] = __uint_as_float(a.w);
-    const float v = __uint_as_float(b.w);
-    out.uv[1] = shader == 0 ? 1.0f - v : v; /* dummy.vert.glsl:25 flips v */
-}
-
-/* The shading phase with the cache: the pixel's word holds its owner and where its corners' tags are. */
-__device__ __forceinline__ void vc_shade(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels, const TileCtx& tc,
-                                         const VtxCache& vc)
-{
-    for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
-        const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
-        if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
-        const size_t pi = (size_t)y * fp.width + (size_t)x;
-        const unsigned long long word = tc.keys[p];
-        const uint32_t owner = (uint32_t)word, packed = (uint32_t)(word >> 32);
-        if (owner == VIS_NONE) { reinterpret_cast<uint32_t*>(fp.color)[pi] = fp.clear_packed; continue; }
-        uint32_t rec[3] = {VC_IDX_NONE, VC_IDX_NONE, VC_IDX_NONE};
-        if (!(packed & VC_PIXEL_UNCACHED)) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rec[c] = vc.tags[(packed >> (VC_POS_BITS * c)) & (VC_TAGS - 1u)] & VC_IDX_NONE;
-        }
-        float rgba[4];
-        if (rec[0] != VC_IDX_NONE && rec[1] != VC_IDX_NONE && rec[2] != VC_IDX_NONE) {
-            /* which draw: only a pass whose draws differ in shader, texture or (push-constant shader) colour needs it */
-            uint32_t draw = 0u;
-            if (!fp.direct_index && (fp.pass_shader < 0 || fp.pass_shader == 2 || fp.pass_texture == -2))
-                draw = fp.prim_rec[owner & SLOT_MASK].draw_flags & SLOT_MASK;
-            int shader, texture;
-            shader_and_texture(fp, draw, shader, texture);
-            Corners c;
-            Varyings v0, v1, v2;
-            vc_corner(vc, rec[0], shader, 0, c, v0);
-            vc_corner(vc, rec[1], shader, 1, c, v1);
-            vc_corner(vc, rec[2], shader, 2, c, v2);
-            shade_fragment(fp, tb, pass_levels, draw, shader, texture, c, v0, v1, v2, nullptr, x, y, rgba);
-        } else {
-            shade_pixel(fp, tb, pass_levels, owner & SLOT_MASK, (owner >> ENTRY_SUB_SHIFT) & 7u, (owner & FLAG_CLIPPED) != 0u, x, y, rgba);
-        }
-        reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, rgba);
-    }
-}
-
-/* The cache is a build option: its LDS (32 KB per workgroup with VC_RECS = 480) is allocated whether a pass uses it or not. */
-#ifndef RND_VTX_CACHE_BUILD
-#define RND_VTX_CACHE_BUILD 0
-#endif
-template <int S> struct CacheStore { uint32_t unused; };
-#if RND_VTX_CACHE_BUILD
-template <> struct CacheStore<1> { VtxCache vc; };
-#endif
-
 /* One workgroup per 32x32 tile, in two phases.  Rasterise the tile's triangles into one 64-bit
  * word per sample held in LDS (depth, submission order, fan index; the minimum wins).  Then every
  * thread takes the tile's pixels one row of eight at a time: depth word and owner of each sample
@@ -1699,7 +1525,6 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     __shared__ unsigned long long keys[TILE_PIXELS * S];
     __shared__ ShadeTables tb;
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
-    __shared__ CacheStore<S> cache_store; /* the vertex cache exists only in the one-sample kernel */
     uint32_t tile, utx, uty;
     if (fp.shard_count == 1) {
         /* the grid covers the tiles the render area touches */
@@ -1729,12 +1554,6 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
     for (uint32_t i = threadIdx.x; i < TILE_PIXELS * S; i += TILE_THREADS) keys[i] = clear_key;
-    if constexpr (S == 1 && RND_VTX_CACHE_BUILD) {
-        if (fp.vtx_cache) {
-            for (uint32_t i = threadIdx.x; i < VC_TAGS; i += TILE_THREADS) cache_store.vc.tags[i] = VC_EMPTY;
-            if (threadIdx.x == 0) cache_store.vc.count = 0u;
-        }
-    }
     __syncthreads();
     RND_STAMP(fp, stamp, 0); /* prologue */
 
@@ -1764,23 +1583,6 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     if (threadIdx.x == 0) fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE] = 0;
     RND_STAMP(fp, stamp, 2); /* waiting for the other waves' rasterisation */
 
-    if constexpr (S == 1 && RND_VTX_CACHE_BUILD) {
-        if (fp.vtx_cache) {
-            VtxCache& vc = cache_store.vc;
-            vc_collect(fp, tc, vc, clear_key);
-            RND_STAMP(fp, stamp, 3);
-            __syncthreads();
-            RND_STAMP(fp, stamp, 4);
-            vc_fill(fp, vc);
-            RND_STAMP(fp, stamp, 5);
-            __syncthreads();
-            RND_STAMP(fp, stamp, 6);
-            vc_shade(fp, tb, (LdsLevels)pass_levels, tc, vc);
-            RND_STAMP(fp, stamp, 7);
-            RND_STAMP_END(fp);
-            return;
-        }
-    }
     for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
         const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
         if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
@@ -1798,7 +1600,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
         }
         shade_and_store<S>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);
     }
-    RND_STAMP(fp, stamp, 8); /* shading without the cache */
+    RND_STAMP(fp, stamp, 8); /* shading */
     RND_STAMP_END(fp);
 }
 

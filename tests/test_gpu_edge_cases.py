@@ -639,22 +639,3 @@ def test_small_write_into_a_shared_uniform_vertex_buffer_reaches_memory(device, 
     sc.vbs[0] = moved
     oc, od, _ = oracle.render_scene(sc, threads=4)
     assert np.array_equal(depth, od) and np.array_equal(color, oc)
-
-
-def test_tile_vertex_cache_on_and_off(device, oracle, monkeypatch):
-    """The tile kernel stages the corners of a tile's visible primitives in LDS; RND_VTX_CACHE=0 at record time keeps
-    the path that gathers them from device memory per pixel (also taken per pixel when a tile's vertices outnumber
-    the cache's records, or a primitive was clipped).  Same frames either way: a mesh whose tiles fit the cache, a
-    mesh of pixel-sized triangles that overflows it, several draws with clipping, the push-constant shader."""
-    cases = [scenes.config1(256, 160, quads=60, tex_size=64),
-             scenes.config1(200, 120, quads=260, tex_size=64),
-             helpers.perspective_soup(256, 160, 500, 11, near_cross=True, shader=scenes.SHADER_TEST_KTX, texture=tex(),
-                                      pipeline_kw=dict(cull_mode=0)),
-             scenes.config0(256, 144, shader=scenes.SHADER_PUSH_CONSTANTS, tex_size=64, segments=24, rings=12)]
-    for sc in cases:
-        oc, od, _ = oracle.render_scene(sc, threads=8)
-        for switch in ("1", "0"):
-            monkeypatch.setenv("RND_VTX_CACHE", switch)
-            color, depth = gpu_render(sc, device)
-            assert np.array_equal(depth, od), (sc.name, switch)
-            assert np.array_equal(color, oc), (sc.name, switch)
