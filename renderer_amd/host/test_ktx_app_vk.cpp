@@ -13,7 +13,9 @@
 // the preferred format (vk_app.cpp:197-221), presenting is rndVkReadFramebuffer.  The mesh and texture are the same
 // procedural stand-ins as in test_ktx_app.cpp of this directory, so both programs print the same checksums.
 //
-//   test_ktx_app_vk_headless [--width W] [--height H] [--frames N] [--out frame.ppm]
+//   test_ktx_app_vk_headless [--width W] [--height H] [--frames N] [--out frame.ppm] [--samples 1|4] [--shader ktx|push_constants]
+// --samples 4 builds the render pass and framebuffer of the obj viewer sample (dummy_obj_viewer_app.cpp:461-639: multisampled colour
+// and depth, resolve into the swapchain image); --shader push_constants is test_push_constants_app.cpp's shader pair and descriptor set.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,7 +49,8 @@ struct vk_model { // obj_loader.hpp:61-89 with Vulkan buffers
 
 class test_ktx_app {
 public:
-    test_ktx_app(uint32_t w, uint32_t h) : m_extent{w, h}
+    test_ktx_app(uint32_t w, uint32_t h, uint32_t samples, bool push_constants_sample)
+        : m_extent{w, h}, m_samples(samples == 4 ? VK_SAMPLE_COUNT_4_BIT : VK_SAMPLE_COUNT_1_BIT), m_push_constants_sample(push_constants_sample)
     {
         m_camera.eye_position = {0, 0, -2}; // base_obj_viewer_app.cpp:12-14
         m_camera.target_position = {0, 0, 0};
@@ -69,6 +72,7 @@ public:
         vkDestroyDescriptorSetLayout(m_device, m_descriptor_set_layout, nullptr);
         for (VkFramebuffer f : m_main_pass_framebuffers) vkDestroyFramebuffer(m_device, f, nullptr);
         vkDestroyImageView(m_device, m_main_depth_image_view, nullptr);
+        vkDestroyImageView(m_device, m_msaa_color_image_view, nullptr);
         for (VkImageView v : m_swapchain_image_views) vkDestroyImageView(m_device, v, nullptr);
         vkDestroyRenderPass(m_device, m_main_render_pass, nullptr);
         vkDestroySampler(m_device, m_sampler, nullptr);
@@ -238,6 +242,26 @@ public:
             .pSubpasses = pass_subpasses,
             .dependencyCount = std::size(pass_deps),
             .pDependencies = pass_deps};
+        // The multisampled pass of the obj viewer sample (dummy_obj_viewer_app.cpp:468-520): attachments {resolve image 1x,
+        // depth 4x, colour 4x}; the subpass draws into attachment 2 and resolves into attachment 0.
+        VkAttachmentDescription msaa_attachments[]{pass_attachments[0], pass_attachments[1], pass_attachments[0]};
+        msaa_attachments[0].loadOp = VK_ATTACHMENT_LOAD_OP_DONT_CARE;
+        msaa_attachments[1].samples = m_samples;
+        msaa_attachments[2].samples = m_samples;
+        msaa_attachments[2].finalLayout = VK_IMAGE_LAYOUT_COLOR_ATTACHMENT_OPTIMAL;
+        VkAttachmentReference msaa_refs[]{
+            {.attachment = 2, .layout = VK_IMAGE_LAYOUT_COLOR_ATTACHMENT_OPTIMAL},
+            {.attachment = 1, .layout = VK_IMAGE_LAYOUT_DEPTH_STENCIL_ATTACHMENT_OPTIMAL},
+            {.attachment = 0, .layout = VK_IMAGE_LAYOUT_COLOR_ATTACHMENT_OPTIMAL}};
+        VkSubpassDescription msaa_subpass = pass_subpasses[0];
+        msaa_subpass.pColorAttachments = msaa_refs;
+        msaa_subpass.pDepthStencilAttachment = msaa_refs + 1;
+        msaa_subpass.pResolveAttachments = msaa_refs + 2;
+        if (m_samples != VK_SAMPLE_COUNT_1_BIT) {
+            pass_info.attachmentCount = std::size(msaa_attachments);
+            pass_info.pAttachments = msaa_attachments;
+            pass_info.pSubpasses = &msaa_subpass;
+        }
         if (vkCreateRenderPass(m_device, &pass_info, nullptr, &m_main_render_pass) != VK_SUCCESS) {
             RAISE_ERROR_FATAL(-1, std::string("cannot init main pass: ") + rndVkLastError());
         }
@@ -246,16 +270,18 @@ public:
 
     ERROR_TYPE init_framebuffers() // :164-258
     {
-        VK_TRY(rndVkCreateAttachmentView(m_device, VK_FORMAT_D24_UNORM_S8_UINT, m_extent.width, m_extent.height, VK_SAMPLE_COUNT_1_BIT, &m_main_depth_image_view), "depth image view");
+        VK_TRY(rndVkCreateAttachmentView(m_device, VK_FORMAT_D24_UNORM_S8_UINT, m_extent.width, m_extent.height, m_samples, &m_main_depth_image_view), "depth image view");
+        if (m_samples != VK_SAMPLE_COUNT_1_BIT) // the multisampled colour image (dummy_obj_viewer_app.cpp:546-600)
+            VK_TRY(rndVkCreateAttachmentView(m_device, m_swapchain_format, m_extent.width, m_extent.height, m_samples, &m_msaa_color_image_view), "multisampled colour image view");
         m_main_pass_framebuffers.reserve(m_swapchain_image_views.size());
         for (size_t i = 0; i < m_swapchain_image_views.size(); ++i) {
-            VkImageView fb_attachments[]{m_swapchain_image_views[i], m_main_depth_image_view};
+            VkImageView fb_attachments[]{m_swapchain_image_views[i], m_main_depth_image_view, m_msaa_color_image_view};
             VkFramebufferCreateInfo fb_info{
                 .sType = VK_STRUCTURE_TYPE_FRAMEBUFFER_CREATE_INFO,
                 .pNext = nullptr,
                 .flags = 0,
                 .renderPass = m_main_render_pass,
-                .attachmentCount = std::size(fb_attachments),
+                .attachmentCount = m_samples != VK_SAMPLE_COUNT_1_BIT ? 3u : 2u,
                 .pAttachments = fb_attachments,
                 .width = m_extent.width,
                 .height = m_extent.height,
@@ -274,8 +300,10 @@ public:
         VkDescriptorSetLayoutBinding bindings[]{
             {.binding = 0, .descriptorType = VK_DESCRIPTOR_TYPE_UNIFORM_BUFFER, .descriptorCount = 1, .stageFlags = VK_SHADER_STAGE_VERTEX_BIT, .pImmutableSamplers = nullptr},
             {.binding = 1, .descriptorType = VK_DESCRIPTOR_TYPE_COMBINED_IMAGE_SAMPLER, .descriptorCount = 1, .stageFlags = VK_SHADER_STAGE_FRAGMENT_BIT, .pImmutableSamplers = nullptr}};
+        // test_push_constants_app.cpp:196-345: the same set without the sampler
+        const uint32_t n_bindings = m_push_constants_sample ? 1u : (uint32_t)std::size(bindings);
         VkDescriptorSetLayoutCreateInfo desc_set_layout_info{
-            .sType = VK_STRUCTURE_TYPE_DESCRIPTOR_SET_LAYOUT_CREATE_INFO, .pNext = nullptr, .flags = 0, .bindingCount = std::size(bindings), .pBindings = bindings};
+            .sType = VK_STRUCTURE_TYPE_DESCRIPTOR_SET_LAYOUT_CREATE_INFO, .pNext = nullptr, .flags = 0, .bindingCount = n_bindings, .pBindings = bindings};
         VK_TRY(vkCreateDescriptorSetLayout(m_device, &desc_set_layout_info, nullptr, &m_descriptor_set_layout), "descriptor set layout");
 
         VkPushConstantRange push_constant_range{.stageFlags = VK_SHADER_STAGE_VERTEX_BIT, .offset = 0, .size = sizeof(push_constant_data)};
@@ -300,14 +328,14 @@ public:
              .descriptorType = VK_DESCRIPTOR_TYPE_UNIFORM_BUFFER, .pImageInfo = nullptr, .pBufferInfo = &buffer_info, .pTexelBufferView = nullptr},
             {.sType = VK_STRUCTURE_TYPE_WRITE_DESCRIPTOR_SET, .pNext = nullptr, .dstSet = m_descriptor_set, .dstBinding = 1, .dstArrayElement = 0, .descriptorCount = 1,
              .descriptorType = VK_DESCRIPTOR_TYPE_COMBINED_IMAGE_SAMPLER, .pImageInfo = &image_info, .pBufferInfo = nullptr, .pTexelBufferView = nullptr}};
-        vkUpdateDescriptorSets(m_device, std::size(write_ops), write_ops, 0, nullptr);
+        vkUpdateDescriptorSets(m_device, n_bindings, write_ops, 0, nullptr);
         RAISE_ERROR_OK();
     }
 
     ERROR_TYPE init_pipelines() // :412-625
     {
-        VK_TRY(rndVkCreateShaderModuleFromFile(m_device, "./shaders/test_ktx.vert.spv", &m_vert_shader), "load_shader");
-        VK_TRY(rndVkCreateShaderModuleFromFile(m_device, "./shaders/test_ktx.frag.spv", &m_frag_shader), "load_shader");
+        VK_TRY(rndVkCreateShaderModuleFromFile(m_device, m_push_constants_sample ? "./shaders/push_constants.vert.spv" : "./shaders/test_ktx.vert.spv", &m_vert_shader), "load_shader");
+        VK_TRY(rndVkCreateShaderModuleFromFile(m_device, m_push_constants_sample ? "./shaders/push_constants.frag.spv" : "./shaders/test_ktx.frag.spv", &m_frag_shader), "load_shader");
         VkPipelineShaderStageCreateInfo shader_stages[]{
             {.sType = VK_STRUCTURE_TYPE_PIPELINE_SHADER_STAGE_CREATE_INFO, .pNext = nullptr, .flags = 0, .stage = VK_SHADER_STAGE_VERTEX_BIT, .module = m_vert_shader, .pName = "main", .pSpecializationInfo = nullptr},
             {.sType = VK_STRUCTURE_TYPE_PIPELINE_SHADER_STAGE_CREATE_INFO, .pNext = nullptr, .flags = 0, .stage = VK_SHADER_STAGE_FRAGMENT_BIT, .module = m_frag_shader, .pName = "main", .pSpecializationInfo = nullptr}};
@@ -324,7 +352,7 @@ public:
             .depthBiasConstantFactor = 0, .depthBiasClamp = 0, .depthBiasSlopeFactor = 0, .lineWidth = 1};
         VkPipelineMultisampleStateCreateInfo multisample_info{
             .sType = VK_STRUCTURE_TYPE_PIPELINE_MULTISAMPLE_STATE_CREATE_INFO, .pNext = nullptr, .flags = 0,
-            .rasterizationSamples = VK_SAMPLE_COUNT_1_BIT, .sampleShadingEnable = VK_FALSE, .minSampleShading = 0,
+            .rasterizationSamples = m_samples, .sampleShadingEnable = VK_FALSE, .minSampleShading = 0,
             .pSampleMask = nullptr, .alphaToCoverageEnable = VK_FALSE, .alphaToOneEnable = VK_FALSE};
         VkPipelineDepthStencilStateCreateInfo depth_stencil_info{
             .sType = VK_STRUCTURE_TYPE_PIPELINE_DEPTH_STENCIL_STATE_CREATE_INFO, .pNext = nullptr, .flags = 0,
@@ -408,7 +436,8 @@ public:
 
         VkClearValue clear_values[]{
             {.color{.float32 = {0.2f, 0.3f, 0.7f, 1.f}}},
-            {.depthStencil = {.depth = 1.0f, .stencil = 0}}};
+            {.depthStencil = {.depth = 1.0f, .stencil = 0}},
+            {.color{.float32 = {0.2f, 0.3f, 0.7f, 1.f}}}}; // the multisampled pass clears its third attachment, the colour image
 
         VkRenderPassBeginInfo pass_begin_info{
             .sType = VK_STRUCTURE_TYPE_RENDER_PASS_BEGIN_INFO,
@@ -418,7 +447,7 @@ public:
             .renderArea = {
                 .offset = {0, 0},
                 .extent = m_extent},
-            .clearValueCount = std::size(clear_values),
+            .clearValueCount = m_samples != VK_SAMPLE_COUNT_1_BIT ? 3u : 2u,
             .pClearValues = clear_values,
         };
 
@@ -549,7 +578,7 @@ public:
     ERROR_TYPE read_back(std::vector<uint8_t>& color, std::vector<uint32_t>& depth)
     {
         color.resize((size_t)m_extent.width * m_extent.height * 4);
-        depth.resize((size_t)m_extent.width * m_extent.height);
+        depth.resize((size_t)m_extent.width * m_extent.height * (size_t)m_samples);
         VK_TRY(vkWaitForFences(m_device, 1, &m_fence, VK_TRUE, UINT64_MAX), "wait for fence");
         VK_TRY(rndVkReadFramebuffer(m_main_pass_framebuffers[0], color.data(), depth.data()), "read framebuffer");
         RAISE_ERROR_OK();
@@ -558,6 +587,8 @@ public:
 private:
     VkExtent2D m_extent;
     VkFormat m_swapchain_format{VK_FORMAT_R8G8B8A8_SRGB};
+    VkSampleCountFlagBits m_samples;
+    bool m_push_constants_sample;
     camera m_camera{};
     VkDevice m_device{VK_NULL_HANDLE};
     VkQueue m_graphics_queue{VK_NULL_HANDLE};
@@ -570,6 +601,7 @@ private:
     VkSampler m_sampler{VK_NULL_HANDLE};
     std::vector<VkImageView> m_swapchain_image_views{};
     VkImageView m_main_depth_image_view{VK_NULL_HANDLE};
+    VkImageView m_msaa_color_image_view{VK_NULL_HANDLE};
     VkRenderPass m_main_render_pass{VK_NULL_HANDLE};
     std::vector<VkFramebuffer> m_main_pass_framebuffers{};
     VkDescriptorSetLayout m_descriptor_set_layout{VK_NULL_HANDLE};
@@ -593,6 +625,8 @@ ERROR_TYPE run(int argc, const char** argv)
 {
     uint32_t w = 1280, h = 720;
     int frames = 3;
+    uint32_t samples = 1;
+    bool push_constants_sample = false;
     std::string out;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -600,9 +634,11 @@ ERROR_TYPE run(int argc, const char** argv)
         else if (a == "--height" && i + 1 < argc) h = (uint32_t)std::atoi(argv[++i]);
         else if (a == "--frames" && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
+        else if (a == "--samples" && i + 1 < argc) samples = (uint32_t)std::atoi(argv[++i]);
+        else if (a == "--shader" && i + 1 < argc) push_constants_sample = std::string(argv[++i]) == "push_constants";
         else RAISE_ERROR_FATAL(-1, "invalid argument " + a);
     }
-    test_ktx_app app(w, h);
+    test_ktx_app app(w, h, samples, push_constants_sample);
     PASS_ERROR(app.on_vulkan_initialized(0));
     app.set_model_scale(0.12f);
     for (int f = 0; f < frames; ++f) {

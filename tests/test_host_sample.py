@@ -89,3 +89,29 @@ def test_sample_frame_matches_oracle(oracle, exe):
     assert int(fields["covered"]) == int((depth != 0xFFFFFF).sum()) > 0
     assert int(fields["depth_fnv"], 16) == fnv1a(depth.astype(np.uint32).tobytes())
     assert int(fields["color_fnv"], 16) == fnv1a(color.tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["samples4", "push_constants", "push_constants_samples4"])
+def test_vulkan_named_sample_variants_match_oracle(oracle, variant):
+    """The sample written against the reference's Vulkan names with the obj viewer's multisampled render pass (three
+    attachments, resolve into the swapchain image: dummy_obj_viewer_app.cpp:461-639) and with the push-constants shader pair
+    and its descriptor set without a sampler (test_push_constants_app.cpp)."""
+    w, h = 256, 144
+    samples = 4 if "samples4" in variant else 1
+    push = "push_constants" in variant
+    args = [SAMPLE_VK, "--frames", "1", "--width", str(w), "--height", str(h), "--samples", str(samples)]
+    if push:
+        args += ["--shader", "push_constants"]
+    out = subprocess.run(args, check=True, capture_output=True, text=True).stdout
+    fields = dict(f.split("=") for f in out.split())
+    ubo, ring = dump_ubo(w, h)
+    sc = scenes.config0(w, h, tex_size=16, samples=samples, shader=scenes.SHADER_PUSH_CONSTANTS if push else scenes.SHADER_TEST_KTX)
+    sc.textures[0]["texels"] = cpp_checker(1024)
+    sc.ubos[0] = ubo
+    for j, d in enumerate(sc.draws):
+        d["push"] = scenes.push_block(hm.RING_COLORS[j], ring[j])
+    color, depth, _ = oracle.render_scene(sc, threads=4)
+    assert int(fields["covered"]) == int((depth != 0xFFFFFF).sum()) > 0
+    assert int(fields["depth_fnv"], 16) == fnv1a(depth.astype(np.uint32).tobytes())
+    assert int(fields["color_fnv"], 16) == fnv1a(color.tobytes())
