@@ -520,8 +520,11 @@ inline void vs_position(const draw_state* ds, uint32_t index, float* clip)
     clip[1] = 1.0f - clip[1];
 }
 
-/* varyings used by the fragment stage: normal (3), uv (2), colour (3) */
-struct varyings { float n[3]; float uv[2]; float col[3]; };
+/* varyings used by the fragment stage: the light term, uv (2), colour (3).
+ * The fragment shaders use v_normal only in dot(v_normal, normalize(vec3(0, 1, -1))) (test_ktx.frag:14-15,
+ * push_constants.frag:12-13).  The dot product is linear in the normal, so it is taken here, at the vertex, and
+ * interpolated: the same value as interpolating the normal and taking the dot per fragment, up to float rounding. */
+struct varyings { float light; float uv[2]; float col[3]; };
 
 inline void vs_varyings(const draw_state* ds, uint32_t index, varyings* out)
 {
@@ -530,7 +533,7 @@ inline void vs_varyings(const draw_state* ds, uint32_t index, varyings* out)
     load_attr(d, index, d->off_nrm, 3, nrm);
     load_attr(d, index, d->off_uv, 2, uv);
     if (d->shader == ORC_SHADER_DUMMY) {
-        out->n[0] = nrm[0]; out->n[1] = nrm[1]; out->n[2] = nrm[2];
+        out->light = 0.0f; /* the dummy shader does not light */
         out->uv[0] = uv[0];
         out->uv[1] = 1.0f - uv[1]; /* dummy.vert.glsl:25 */
         out->col[0] = out->col[1] = out->col[2] = 0.0f;
@@ -538,7 +541,11 @@ inline void vs_varyings(const draw_state* ds, uint32_t index, varyings* out)
         float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
         float len = sqrtf(len2);
         float nn[3] = {nrm[0] / len, nrm[1] / len, nrm[2] / len};
-        mat3_vec(ds->nrm_m, nn, out->n);
+        float tn[3];
+        mat3_vec(ds->nrm_m, nn, tn); /* v_normal (test_ktx.vert:30) */
+        /* normalize(vec3(0,1,-1)) as float constants */
+        const float lx = 0.0f, ly = 0.70710678118654752f, lz = -0.70710678118654752f;
+        out->light = fma32(tn[2], lz, fma32(tn[1], ly, tn[0] * lx));
         out->uv[0] = uv[0]; out->uv[1] = uv[1];
         out->col[0] = d->push[0]; out->col[1] = d->push[1]; out->col[2] = d->push[2];
     }
@@ -680,11 +687,7 @@ void shade_fragment(const draw_state* ds, const orc_texture* textures, int n_tex
         rgba[0] = tex[0]; rgba[1] = tex[1]; rgba[2] = tex[2]; rgba[3] = 1.0f; /* dummy.frag.glsl:13 */
         return;
     }
-    float n[3] = {interp(lam, v[0].n[0], v[1].n[0], v[2].n[0]), interp(lam, v[0].n[1], v[1].n[1], v[2].n[1]),
-                  interp(lam, v[0].n[2], v[1].n[2], v[2].n[2])};
-    /* normalize(vec3(0,1,-1)) as float constants */
-    const float lx = 0.0f, ly = 0.70710678118654752f, lz = -0.70710678118654752f;
-    float diff = fmaxf(fma32(n[2], lz, fma32(n[1], ly, n[0] * lx)), 0.0f);
+    float diff = fmaxf(interp(lam, v[0].light, v[1].light, v[2].light), 0.0f);
     if (d->shader == ORC_SHADER_TEST_KTX) {
         rgba[0] = tex[0] * diff; rgba[1] = tex[1] * diff; rgba[2] = tex[2] * diff; /* test_ktx.frag:16 */
     } else {

@@ -102,17 +102,15 @@ struct SVtx {
     float iw;    /* 1/w */
 };
 
-/* Vertex-shader outputs besides the position: 20 bytes, packed (a record starts on a 4-byte boundary); shading reads
- * a corner's record as one 16-byte load and one word */
+/* What shading needs of a vertex besides its position: 12 bytes, read as one load per corner.
+ * `light` is dot(v_normal, normalize(vec3(0, 1, -1))) (test_ktx.frag:14-15, push_constants.frag:12-13) taken at the
+ * vertex: the dot product is linear in the normal, so interpolating it is interpolating the normal and taking the
+ * dot per fragment, up to float rounding -- and the record holds one float where the normal would take three. */
 struct SVary {
-    float nx, ny, nz; /* v_normal (zero for the dummy shader, which does not light) */
+    float light;      /* zero for the dummy shader, which does not light */
     float u, v;       /* a_uv as stored */
-#ifdef RND_SVARY_PAD
-    float pad[3];
-#endif
 };
-/* the first four words of a record as one load; the address is a multiple of 4, not of 16 */
-struct __attribute__((aligned(4))) SVaryHead { float x, y, z, w; };
+static_assert(sizeof(SVary) == 12, "packed");
 
 /* Per-draw record, immutable after recording */
 struct DrawStatic {

@@ -412,14 +412,16 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     fp.svtx[d.svtx_base + v] = out;
     /* the rest of the vertex shader: v_normal (test_ktx.vert:30, push_constants.vert:30) and v_uv */
     SVary vo;
-    vo.nx = vo.ny = vo.nz = 0.0f; vo.u = uv[0]; vo.v = uv[1];
+    vo.light = 0.0f; vo.u = uv[0]; vo.v = uv[1];
     if (d.shader != 0) {
         const float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
         const float len = sqrtf(len2);
         const float nn[3] = {nrm[0] / len, nrm[1] / len, nrm[2] / len};
         float tn[3];
         mat3_vec(nm, nn, tn);
-        vo.nx = tn[0]; vo.ny = tn[1]; vo.nz = tn[2];
+        /* the light term of the fragment shaders, at the vertex (see SVary) */
+        const float lx = 0.0f, ly = 0.70710678118654752f, lz = -0.70710678118654752f;
+        vo.light = fma32(tn[2], lz, fma32(tn[1], ly, tn[0] * lx));
     }
     fp.svary[d.svtx_base + v] = vo;
     RND_KERNEL_END(fp, 0u);
@@ -935,16 +937,15 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
 
 /* ---- fragment stage ---- */
 
-struct Varyings { float n[3]; float uv[2]; };
+struct Varyings { float light; float uv[2]; };
 
 /* Vertex-shader outputs other than the position, as the vertex kernel left them */
 __device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vtx, int shader, Varyings& out)
 {
-    const SVaryHead a = *reinterpret_cast<const SVaryHead*>(&fp.svary[vtx]);
-    const float v = fp.svary[vtx].v;
-    out.n[0] = a.x; out.n[1] = a.y; out.n[2] = a.z;
-    out.uv[0] = a.w;
-    out.uv[1] = shader == 0 ? 1.0f - v : v; /* dummy.vert.glsl:25 flips v */
+    const SVary a = fp.svary[vtx]; /* three adjacent words: one 12-byte load */
+    out.light = a.light;
+    out.uv[0] = a.u;
+    out.uv[1] = shader == 0 ? 1.0f - a.v : a.v; /* dummy.vert.glsl:25 flips v */
 }
 
 __device__ __forceinline__ float interp(const float* lam, float a0, float a1, float a2)
@@ -1326,9 +1327,7 @@ __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Shad
         }
     }
     if (shader == 0) { rgba[0] = tex[0]; rgba[1] = tex[1]; rgba[2] = tex[2]; rgba[3] = 1.0f; return; }
-    float n[3] = {interp(lam, v0.n[0], v1.n[0], v2.n[0]), interp(lam, v0.n[1], v1.n[1], v2.n[1]), interp(lam, v0.n[2], v1.n[2], v2.n[2])};
-    const float lx = 0.0f, ly = 0.70710678118654752f, lz = -0.70710678118654752f;
-    float diff = fmaxf(fma32(n[2], lz, fma32(n[1], ly, n[0] * lx)), 0.0f);
+    const float diff = fmaxf(interp(lam, v0.light, v1.light, v2.light), 0.0f);
     if (shader == 1) {
         rgba[0] = tex[0] * diff; rgba[1] = tex[1] * diff; rgba[2] = tex[2] * diff;
     } else {
