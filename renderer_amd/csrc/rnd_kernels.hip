@@ -571,7 +571,13 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
 {
     __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
     RND_KERNEL_BEGIN(fp, 1);
-    const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+    /* Workgroups are dealt round-robin over the 8 XCDs.  In a pass of one draw -- a mesh, whose neighbouring chunks of
+     * primitives share vertices and append to the same tile lists -- each XCD takes a contiguous eighth of the chunks, so
+     * that neighbours meet in one L2 (the grid is then a multiple of 8 workgroups).  A pass of many small draws keeps
+     * the plain order: measured slower there, its draws being scattered over the screen anyway. */
+    uint32_t block = blockIdx.x;
+    if (fp.direct_index) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t chunk = wave_uniform(block * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_tchunks) return;
     /* a pass without a chunk table is one draw whose chunks are its triangles in order */
     const Chunk c = fp.tchunks ? fp.tchunks[chunk] : Chunk{0u, chunk * 64u};
@@ -1693,7 +1699,9 @@ void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t
 void launch_setup(const FrameParams& fp, hipStream_t s)
 {
     if (!fp.n_tchunks) return;
-    hipLaunchKernelGGL(k_setup, dim3((fp.n_tchunks + 3) / 4), dim3(256), 0, s, fp);
+    uint32_t blocks = (fp.n_tchunks + 3) / 4;
+    if (fp.direct_index) blocks = ((blocks + 7) / 8) * 8; /* one share per XCD */
+    hipLaunchKernelGGL(k_setup, dim3(blocks), dim3(256), 0, s, fp);
 }
 
 void launch_tile(const FrameParams& fp, hipStream_t s)
