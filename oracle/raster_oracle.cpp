@@ -794,8 +794,10 @@ void render_band(const band_job* job)
                                 bool in1 = e1 > 0 || (e1 == 0 && own1);
                                 bool in2 = e2 > 0 || (e2 == 0 && own2);
                                 if (!(in0 && in1 && in2)) continue;
-                                float b1 = (float)e1 * t->inv_area, b2 = (float)e2 * t->inv_area;
-                                float z = fma32(b2, t->v[2].z - t->v[0].z, fma32(b1, t->v[1].z - t->v[0].z, t->v[0].z));
+                                /* depth is affine over the window: z0 plus the edge functions of corners 1 and 2 times
+                                 * the depth's change per unit of each (a fragment costs two multiply-adds) */
+                                float gz1 = (t->v[1].z - t->v[0].z) * t->inv_area, gz2 = (t->v[2].z - t->v[0].z) * t->inv_area;
+                                float z = fma32((float)e2, gz2, fma32((float)e1, gz1, t->v[0].z));
                                 uint32_t dz = depth24(z);
                                 size_t gi = ((size_t)y * W + x) * S + s;
                                 size_t li = ((size_t)(y - job->y0) * W + x) * S + s;

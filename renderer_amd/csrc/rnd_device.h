@@ -56,8 +56,7 @@ __device__ __forceinline__ int32_t snap(float v)
 __device__ __forceinline__ uint32_t depth24(float z)
 {
     z = fminf(fmaxf(z, 0.0f), 1.0f);
-    uint32_t d = (uint32_t)__builtin_rintf(z * 16777215.0f);
-    return d > 0xFFFFFFu ? 0xFFFFFFu : d;
+    return (uint32_t)__builtin_rintf(z * 16777215.0f); /* z <= 1, so the product is at most 2^24 - 1, which is a float */
 }
 
 /* linear -> sRGB code: number of thresholds <= c; the bucket table gives a

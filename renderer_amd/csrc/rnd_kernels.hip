@@ -667,9 +667,8 @@ struct EdgeSetup {
     I ax0, ay0, ax1, ay1, ax2, ay2;
     I dx0, dy0, dx1, dy1, dx2, dy2;
     I bias0, bias1, bias2;
-    float z0, dz1, dz2, inv_area;
-    unsigned long long payload;
-    uint32_t depth_test;
+    float z0, gz1, gz2;     /* depth at corner 0 and its change per unit of edge functions 1 and 2 */
+    uint32_t pay_lo, pay_hi; /* the low 40 bits of a fragment's word: order and fan index */
 
     __device__ __forceinline__ void init(const FrameParams& fp, const RasterTri& t)
     {
@@ -683,21 +682,21 @@ struct EdgeSetup {
         bias1 = owns_edge(t.x[2], t.y[2], t.x[0], t.y[0]) ? 0 : 1;
         bias2 = owns_edge(t.x[0], t.y[0], t.x[1], t.y[1]) ? 0 : 1;
         const I area2 = edge_mul(dx2, (I)t.y[2] - (I)t.y[0]) - edge_mul(dy2, (I)t.x[2] - (I)t.x[0]);
-        inv_area = recip32((float)area2);
-        z0 = t.z[0]; dz1 = t.z[1] - t.z[0]; dz2 = t.z[2] - t.z[0];
+        const float inv_area = recip32((float)area2);
+        z0 = t.z[0]; gz1 = (t.z[1] - t.z[0]) * inv_area; gz2 = (t.z[2] - t.z[0]) * inv_area;
+        if (!fp.depth_test) z0 = gz1 = gz2 = 0.0f; /* no depth test: every fragment's depth is 0 and the order decides */
         const uint32_t ord = fp.depth_less ? t.slot : ~t.slot;
-        payload = ((unsigned long long)ord << 8) | (unsigned long long)t.payload_lo;
-        depth_test = fp.depth_test;
+        pay_lo = (ord << 8) | t.payload_lo;
+        pay_hi = ord >> 24;
     }
 
     /* depth of a covered sample from its edge values, then the LDS minimum.  No read first:
      * the atomic needs no result, so the lane does not wait for the LDS */
     __device__ __forceinline__ void emit(const TileCtx& tc, uint32_t word_index, I e1, I e2) const
     {
-        const float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
-        const float z = fma32(b2, dz2, fma32(b1, dz1, z0));
-        const uint32_t d24 = depth_test ? depth24(z) : 0u;
-        atomicMin(&tc.keys[word_index], ((unsigned long long)d24 << 40) | payload);
+        const float z = fma32((float)e2, gz2, fma32((float)e1, gz1, z0));
+        const uint32_t hi = (depth24(z) << 8) | pay_hi;
+        atomicMin(&tc.keys[word_index], ((unsigned long long)hi << 32) | pay_lo);
     }
 
     __device__ __forceinline__ void pixel(const TileCtx& tc, int x, int y) const

@@ -11,4 +11,4 @@ ln -s $ROOT/include $W/include
 cp $ROOT/renderer_amd/csrc/*.h $ROOT/renderer_amd/csrc/*.hip $ROOT/renderer_amd/csrc/*.cpp $W/renderer_amd/csrc/
 for f in "$@"; do cp "$f" $W/renderer_amd/csrc/$(basename "$f" | sed 's/^[^.]*__//'); done
 cd $W/renderer_amd/csrc
-hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 $EXTRA -shared -o $ROOT/build/lib_$NAME.so rnd_kernels.hip rnd_abi.cpp
+hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 ${TRACKERS--mllvm -amdgpu-use-amdgpu-trackers=1} $EXTRA -shared -o $ROOT/build/lib_$NAME.so rnd_kernels.hip rnd_abi.cpp
