@@ -44,6 +44,14 @@ __device__ __forceinline__ float recip32(float x)
     return 1.0f / x;
 }
 
+/* the same for an x known to be a non-zero integer below 2^63 in magnitude (a triangle's doubled area in
+ * 24.8 units): always in the range where the refined estimate is the quotient, so no test */
+__device__ __forceinline__ float recip32_of_area(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fma32(fma32(-x, r, 1.0f), r, r);
+}
+
 /* window coordinate -> 24.8: floor(fma(v, 256, 0.5)) */
 __device__ __forceinline__ int32_t snap(float v)
 {

@@ -682,7 +682,7 @@ struct EdgeSetup {
         bias1 = owns_edge(t.x[2], t.y[2], t.x[0], t.y[0]) ? 0 : 1;
         bias2 = owns_edge(t.x[0], t.y[0], t.x[1], t.y[1]) ? 0 : 1;
         const I area2 = edge_mul(dx2, (I)t.y[2] - (I)t.y[0]) - edge_mul(dy2, (I)t.x[2] - (I)t.x[0]);
-        const float inv_area = recip32((float)area2);
+        const float inv_area = recip32_of_area((float)area2); /* setup lists no triangle of zero area */
         z0 = t.z[0]; gz1 = (t.z[1] - t.z[0]) * inv_area; gz2 = (t.z[2] - t.z[0]) * inv_area;
         if (!fp.depth_test) z0 = gz1 = gz2 = 0.0f; /* no depth test: every fragment's depth is 0 and the order decides */
         const uint32_t ord = fp.depth_less ? t.slot : ~t.slot;
@@ -885,11 +885,11 @@ __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileC
         const int ox0 = __shfl(x0, o), oy0 = __shfl(y0, o), ow = __shfl(w, o), oarea = __shfl(area, o), ofirst = __shfl(excl, o);
         if (c >= total) continue;
         const int k0 = (c - ofirst) * CHUNK_PIXELS, k1 = min(k0 + CHUNK_PIXELS, oarea);
-        /* row and column of pixel k0: k0 / ow by a 16-bit reciprocal, exact for k0 < 1024 and ow <= 32
-         * (65536 / ow is an integer only for powers of two, where the float quotient is exact) */
-        const uint32_t recip = (uint32_t)ceilf(65536.0f / (float)ow);
-        const int row = (int)(((uint32_t)k0 * recip) >> 16);
+        /* row and column of pixel k0 (k0 < 1024, ow <= 32): the float quotient by the hardware's reciprocal
+         * estimate, whose error is far below one, put right by the remainder */
+        int row = (int)((float)k0 * __builtin_amdgcn_rcpf((float)ow)); /* within one of k0 / ow */
         int col = k0 - row * ow;
+        if (col < 0) { --row; col += ow; } else if (col >= ow) { ++row; col -= ow; }
         EdgeSetup<int32_t, S> es;
         es.init(fp, u);
         if constexpr (S == 1) {
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void corner_weights(const Corners& c, int x, int y, b
     }
     EdgeFloats t;
     t.swapped = fs < 0.0f;
-    t.inv_s = recip32(fs);
+    t.inv_s = recip32_of_area(fs); /* a shaded pixel has a sample inside the triangle: the area is not zero */
     t.iw[0] = c.iw[0]; t.iw[1] = c.iw[1]; t.iw[2] = c.iw[2];
     weights_at(t, fe[0], fe[1], fe[2], q);
     if (want_derivs) {
