@@ -715,6 +715,74 @@ struct EdgeSetup {
     }
 };
 
+/* What a single-sample walk over part of a small triangle's box needs, whichever part it is: the three edge
+ * values at the box's first pixel (ownership bias folded in: covered <=> none negative), their steps per pixel
+ * right and down, the depth plane and the fragment word's low bits.  Taken once per triangle by the lane that
+ * holds it; a lane that is dealt a chunk of the box fetches these sixteen words from that lane instead of the
+ * triangle's corners, and starts its walk with six multiply-adds. */
+struct WalkSetup {
+    int32_t e0, e1, e2;     /* at the box's first pixel */
+    int32_t sx0, sx1, sx2;  /* one pixel right */
+    int32_t sy0, sy1, sy2;  /* one pixel down */
+    float z0, gz1, gz2;
+    uint32_t pay_lo, pay_hi;
+    uint32_t box;           /* bits 0..4 first column in the tile, 5..9 first row, 10..14 width - 1, 15..25 pixels, 26/27 bias of edges 1/2 */
+
+    __device__ __forceinline__ void init(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int w, int area)
+    {
+        EdgeSetup<int32_t, 1> es;
+        es.init(fp, t);
+        const int32_t px = x0 * 256 + 128, py = y0 * 256 + 128;
+        e0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0) - es.bias0;
+        e1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1) - es.bias1;
+        e2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2) - es.bias2;
+        sx0 = -(es.dy0 << 8); sx1 = -(es.dy1 << 8); sx2 = -(es.dy2 << 8);
+        sy0 = es.dx0 << 8; sy1 = es.dx1 << 8; sy2 = es.dx2 << 8;
+        z0 = es.z0; gz1 = es.gz1; gz2 = es.gz2; pay_lo = es.pay_lo; pay_hi = es.pay_hi;
+        box = (uint32_t)(x0 - tc.px0) | ((uint32_t)(y0 - tc.py0) << 5) | ((uint32_t)(w - 1) << 10) | ((uint32_t)area << 15) |
+              ((uint32_t)es.bias1 << 26) | ((uint32_t)es.bias2 << 27);
+    }
+
+    __device__ __forceinline__ WalkSetup from_lane(int o) const
+    {
+        WalkSetup u;
+        u.e0 = __shfl(e0, o); u.e1 = __shfl(e1, o); u.e2 = __shfl(e2, o);
+        u.sx0 = __shfl(sx0, o); u.sx1 = __shfl(sx1, o); u.sx2 = __shfl(sx2, o);
+        u.sy0 = __shfl(sy0, o); u.sy1 = __shfl(sy1, o); u.sy2 = __shfl(sy2, o);
+        u.z0 = __shfl(z0, o); u.gz1 = __shfl(gz1, o); u.gz2 = __shfl(gz2, o);
+        u.pay_lo = (uint32_t)__shfl((int)pay_lo, o); u.pay_hi = (uint32_t)__shfl((int)pay_hi, o);
+        u.box = (uint32_t)__shfl((int)box, o);
+        return u;
+    }
+
+    /* pixels k0 .. k1-1 of the box, in row order */
+    __device__ __forceinline__ void walk(const TileCtx& tc, int k0, int k1) const
+    {
+        const int ow = (int)((box >> 10) & 31u) + 1;
+        const int32_t b1 = (int32_t)((box >> 26) & 1u), b2 = (int32_t)((box >> 27) & 1u);
+        /* row and column of pixel k0 (k0 < 1024, ow <= 32): the float quotient by the hardware's reciprocal
+         * estimate, whose error is far below one, put right by the remainder */
+        int row = (int)((float)k0 * __builtin_amdgcn_rcpf((float)ow));
+        int col = k0 - row * ow;
+        if (col < 0) { --row; col += ow; } else if (col >= ow) { ++row; col -= ow; }
+        int32_t a0 = e0 + __mul24(col, sx0) + __mul24(row, sy0);
+        int32_t a1 = e1 + __mul24(col, sx1) + __mul24(row, sy1);
+        int32_t a2 = e2 + __mul24(col, sx2) + __mul24(row, sy2);
+        /* from the last pixel of a row to the first of the next: one down, ow - 1 back */
+        const int32_t nl0 = sy0 - __mul24(ow - 1, sx0), nl1 = sy1 - __mul24(ow - 1, sx1), nl2 = sy2 - __mul24(ow - 1, sx2);
+        uint32_t pix = (((box >> 5) & 31u) + (uint32_t)row) * TILE_W + (box & 31u) + (uint32_t)col;
+        EdgeSetup<int32_t, 1> es; /* only its depth plane is used */
+        es.z0 = z0; es.gz1 = gz1; es.gz2 = gz2; es.pay_lo = pay_lo; es.pay_hi = pay_hi;
+        for (int i = k0; i < k1; ++i) {
+            if ((a0 | a1 | a2) >= 0) es.emit(tc, pix, a1 + b1, a2 + b2);
+            const bool last = ++col == ow;
+            a0 += last ? nl0 : sx0; a1 += last ? nl1 : sx1; a2 += last ? nl2 : sx2;
+            pix += last ? (uint32_t)(TILE_W - ow + 1) : 1u;
+            if (last) col = 0;
+        }
+    }
+};
+
 /* Multisample walk of pixels k0 .. k1-1 (row order) of a box whose first pixel is (x0, y0) and whose
  * width is w, starting at (row, col).  The edge values are stepped per pixel at the pixel's corner;
  * a sample's value is the corner's plus a constant per edge and sample (ownership bias folded in),
@@ -866,6 +934,8 @@ __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileC
     }
     const int excl = incl - n;
     const int total = __shfl(incl, 63);
+    WalkSetup mine;
+    if constexpr (S == 1) mine.init(fp, tc, t, x0, y0, active ? w : 1, area);
     for (int base = 0; base < total; base += 64) {
         const int c = base + lane;
         /* owner: the last lane whose first chunk number is not above c (lanes without chunks share
@@ -877,37 +947,26 @@ __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileC
             const int first = __shfl(excl, cand & 63);
             if (cand < 64 && first <= c) o = cand;
         }
-        RasterTri u;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { u.x[k] = __shfl(t.x[k], o); u.y[k] = __shfl(t.y[k], o); u.z[k] = __shfl(t.z[k], o); }
-        u.payload_lo = (uint32_t)__shfl((int)t.payload_lo, o);
-        u.slot = (uint32_t)__shfl((int)t.slot, o);
-        const int ox0 = __shfl(x0, o), oy0 = __shfl(y0, o), ow = __shfl(w, o), oarea = __shfl(area, o), ofirst = __shfl(excl, o);
-        if (c >= total) continue;
-        const int k0 = (c - ofirst) * CHUNK_PIXELS, k1 = min(k0 + CHUNK_PIXELS, oarea);
-        /* row and column of pixel k0 (k0 < 1024, ow <= 32): the float quotient by the hardware's reciprocal
-         * estimate, whose error is far below one, put right by the remainder */
-        int row = (int)((float)k0 * __builtin_amdgcn_rcpf((float)ow)); /* within one of k0 / ow */
-        int col = k0 - row * ow;
-        if (col < 0) { --row; col += ow; } else if (col >= ow) { ++row; col -= ow; }
-        EdgeSetup<int32_t, S> es;
-        es.init(fp, u);
         if constexpr (S == 1) {
-            const int32_t px = (ox0 + col) * 256 + 128, py = (oy0 + row) * 256 + 128;
-            int32_t e0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0) - es.bias0;
-            int32_t e1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1) - es.bias1;
-            int32_t e2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2) - es.bias2;
-            const int32_t sx0 = -(es.dy0 << 8), sx1 = -(es.dy1 << 8), sx2 = -(es.dy2 << 8);
-            const int32_t nl0 = (es.dx0 << 8) - (ow - 1) * sx0, nl1 = (es.dx1 << 8) - (ow - 1) * sx1, nl2 = (es.dx2 << 8) - (ow - 1) * sx2;
-            uint32_t pix = (uint32_t)((oy0 + row - tc.py0) * TILE_W + (ox0 + col - tc.px0));
-            for (int i = k0; i < k1; ++i) {
-                if ((e0 | e1 | e2) >= 0) es.emit(tc, pix, e1 + es.bias1, e2 + es.bias2);
-                const bool last = ++col == ow;
-                e0 += last ? nl0 : sx0; e1 += last ? nl1 : sx1; e2 += last ? nl2 : sx2;
-                pix += last ? (uint32_t)(TILE_W - ow + 1) : 1u;
-                if (last) col = 0;
-            }
+            const WalkSetup u = mine.from_lane(o);
+            const int ofirst = __shfl(excl, o);
+            if (c >= total) continue;
+            const int k0 = (c - ofirst) * CHUNK_PIXELS, k1 = min(k0 + CHUNK_PIXELS, (int)((u.box >> 15) & 2047u));
+            u.walk(tc, k0, k1);
         } else {
+            RasterTri u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { u.x[k] = __shfl(t.x[k], o); u.y[k] = __shfl(t.y[k], o); u.z[k] = __shfl(t.z[k], o); }
+            u.payload_lo = (uint32_t)__shfl((int)t.payload_lo, o);
+            u.slot = (uint32_t)__shfl((int)t.slot, o);
+            const int ox0 = __shfl(x0, o), oy0 = __shfl(y0, o), ow = __shfl(w, o), oarea = __shfl(area, o), ofirst = __shfl(excl, o);
+            if (c >= total) continue;
+            const int k0 = (c - ofirst) * CHUNK_PIXELS, k1 = min(k0 + CHUNK_PIXELS, oarea);
+            int row = (int)((float)k0 * __builtin_amdgcn_rcpf((float)ow)); /* within one of k0 / ow */
+            int col = k0 - row * ow;
+            if (col < 0) { --row; col += ow; } else if (col >= ow) { ++row; col -= ow; }
+            EdgeSetup<int32_t, S> es;
+            es.init(fp, u);
             walk_samples<S>(es, tc, ox0, oy0, ow, k0, k1, row, col);
         }
     }
