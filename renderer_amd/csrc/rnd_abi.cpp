@@ -514,12 +514,15 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
     for (int k = 1; k < 256; ++k) host_tables.thr[k] = (float)srgb_to_linear((k - 0.5) / 255.0);
     host_tables.thr[256] = INFINITY;
     for (uint32_t i = 0; i < SRGB_LUT_SIZE; ++i) {
-        uint32_t bits = (i + SRGB_LUT_FIRST) << 16;
-        float c;
+        uint32_t bits = (i + SRGB_LUT_FIRST) << SRGB_LUT_SHIFT, next_bits = (i + 1 + SRGB_LUT_FIRST) << SRGB_LUT_SHIFT;
+        float c, next;
         memcpy(&c, &bits, 4);
+        memcpy(&next, &next_bits, 4);
         uint32_t k = 0;
         while (k < 255 && host_tables.thr[k + 1] <= c) ++k;
         host_tables.lut[i] = (uint8_t)k;
+        /* the encoder looks at one threshold after the table's answer: a bucket may hold only one */
+        if (k < 254 && host_tables.thr[k + 2] < next) { rnd_device_destroy(dev); return fail(RND_ERROR_INITIALIZATION_FAILED, "sRGB bucket table: two thresholds in one bucket"); }
     }
     if (hipMalloc(reinterpret_cast<void**>(&dev->tables), sizeof(ShadeTables)) != hipSuccess) {
         rnd_device_destroy(dev);

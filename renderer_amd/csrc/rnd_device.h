@@ -67,16 +67,14 @@ __device__ __forceinline__ uint32_t depth24(float z)
     return (uint32_t)__builtin_rintf(z * 16777215.0f); /* z <= 1, so the product is at most 2^24 - 1, which is a float */
 }
 
-/* linear -> sRGB code: number of thresholds <= c; the bucket table gives a
- * lower bound that is at most two short */
+/* linear -> sRGB code: number of thresholds <= c; the bucket table gives the number of thresholds <= the
+ * bucket's lower edge, and a bucket holds at most one threshold (checked where the table is built) */
 __device__ __forceinline__ uint32_t srgb_encode(const ShadeTables& tb, float c)
 {
     if (!(c >= tb.thr[1])) return 0; /* also NaN */
     if (c >= tb.thr[255]) return 255;
-    uint32_t key = (__float_as_uint(c) >> 16) - SRGB_LUT_FIRST; /* c in [thr[1], thr[255]) lies inside [2^-13, 1) */
+    uint32_t key = (__float_as_uint(c) >> SRGB_LUT_SHIFT) - SRGB_LUT_FIRST; /* c in [thr[1], thr[255]) lies inside [2^-13, 1) */
     uint32_t k = tb.lut[key];
-    k += (c >= tb.thr[k + 1]) ? 1u : 0u;
-    k += (c >= tb.thr[k + 1]) ? 1u : 0u;
     k += (c >= tb.thr[k + 1]) ? 1u : 0u;
     return k;
 }

@@ -39,8 +39,9 @@ enum : uint32_t {
 constexpr uint32_t BBOX_CULLED = 0x000000FFu; /* tx0=255 > tx1=0: nothing to draw */
 
 /* float bits [2^-13, 1) >> 16: 13 octaves x 128 buckets */
-constexpr uint32_t SRGB_LUT_FIRST = 0x39000000u >> 16; /* 2^-13 */
-constexpr uint32_t SRGB_LUT_LAST = 0x3F800000u >> 16;  /* 1.0 */
+constexpr uint32_t SRGB_LUT_SHIFT = 15;                 /* a bucket per exponent and top eight mantissa bits: no bucket holds two thresholds */
+constexpr uint32_t SRGB_LUT_FIRST = 0x39000000u >> SRGB_LUT_SHIFT; /* 2^-13 */
+constexpr uint32_t SRGB_LUT_LAST = 0x3F800000u >> SRGB_LUT_SHIFT;  /* 1.0 */
 constexpr uint32_t SRGB_LUT_SIZE = SRGB_LUT_LAST - SRGB_LUT_FIRST;
 
 /* Texel tables, staged in LDS by the kernels that shade: value[0][k] = linear value of sRGB code k,
