@@ -1295,6 +1295,7 @@ int rnd_cmd_end(rnd_cmd cmd)
      * still clears the render area) */
     if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
     fp.direct_index = n == 1 ? 1u : 0u;
+    if (n == 1) { fp.direct_ib = ds[0].ib; fp.direct_svtx_base = ds[0].svtx_base; }
     fp.pass_shader = n ? ds[0].shader : -1;
     fp.pass_texture = n ? ds[0].texture : -1;
     for (size_t i = 1; i < n; ++i) {
@@ -1446,7 +1447,7 @@ int rnd_draw_indexed_noalloc(rnd_device dev, const rnd_noalloc_draw* dr, rnd_fen
     fp.large_capacity = NA_LARGE_CAPACITY; fp.clip_tri_capacity = NA_CLIP_TRI_CAPACITY;
     /* one draw: its chunks are its vertices and triangles in order, no chunk tables (vchunks / tchunks stay null) */
     fp.n_draws = 1; fp.n_vchunks = (d.vert_count + CHUNK - 1) / CHUNK; fp.n_tchunks = (tri_count + CHUNK - 1) / CHUNK;
-    fp.direct_index = 1u;
+    fp.direct_index = 1u; fp.direct_ib = d.ib; fp.direct_svtx_base = d.svtx_base;
     const int depth_test = pi.depth_test ? 1 : 0, depth_less = (pi.depth_test && pi.depth_compare == RND_COMPARE_LESS) ? 1 : 0;
     const int32_t area[4] = {0, 0, (int32_t)tg->width, (int32_t)tg->height};
     pass_params(fp, dev, tg, area, true, vp, dr->scissor, dr->clear_color, dr->clear_depth, depth_test, depth_less);

@@ -251,6 +251,8 @@ struct FrameParams {
     uint32_t depth_test, depth_write;
     uint32_t direct_index;   /* 1: the pass is one draw, so a primitive's slot is its triangle number and shading reads the
                                 index buffer itself; unclipped primitives then get no PrimRec */
+    const uint32_t* direct_ib;     /* direct_index: the one draw's index buffer and first svtx[] record, by value (shading reads */
+    uint32_t direct_svtx_base;     /* them per pixel: kernel arguments, not a load from the draw's record) */
     int32_t pass_shader;     /* shader of every draw of the pass, or -1 when they differ */
     int32_t pass_texture;    /* texture index of every draw (-1: none bound), or -2 when they differ */
     TexDesc pass_tex;        /* textures[pass_texture] by value */

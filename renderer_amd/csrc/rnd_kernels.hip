@@ -1420,9 +1420,8 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
     PrimRec pr;
     if (fp.direct_index && !clipped) {
         /* a pass of one draw: the slot is the triangle's number, its corners come from the index buffer */
-        const DrawStatic& d = fp.draws[0];
-        const uint32_t* ip = d.ib + (size_t)slot * 3;
-        pr.v0 = d.svtx_base + load_u32(ip); pr.v1 = d.svtx_base + load_u32(ip + 1); pr.v2 = d.svtx_base + load_u32(ip + 2);
+        const uint32_t* ip = fp.direct_ib + (size_t)slot * 3;
+        pr.v0 = fp.direct_svtx_base + load_u32(ip); pr.v1 = fp.direct_svtx_base + load_u32(ip + 1); pr.v2 = fp.direct_svtx_base + load_u32(ip + 2);
         pr.draw_flags = 0;
     } else {
         pr = fp.prim_rec[slot];
@@ -1444,10 +1443,14 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
     Corners c;
     const float* bary = nullptr;
     if (!clipped) {
-        const SVtx p0 = fp.svtx[vtx[0]], p1 = fp.svtx[vtx[1]], p2 = fp.svtx[vtx[2]];
-        c.x[0] = p0.xf >> 8; c.y[0] = p0.y; c.iw[0] = p0.iw;
-        c.x[1] = p1.xf >> 8; c.y[1] = p1.y; c.iw[1] = p1.iw;
-        c.x[2] = p2.xf >> 8; c.y[2] = p2.y; c.iw[2] = p2.iw;
+        /* each corner as one 16-byte load, said explicitly: left as member reads, the compiler folds them with the
+         * clipped branch's reads into nine single-word loads through selected pointers */
+        typedef uint32_t Record __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) Record* GlobalRecord;
+        const Record p0 = *(GlobalRecord)&fp.svtx[vtx[0]], p1 = *(GlobalRecord)&fp.svtx[vtx[1]], p2 = *(GlobalRecord)&fp.svtx[vtx[2]];
+        c.x[0] = (int32_t)p0.x >> 8; c.y[0] = (int32_t)p0.y; c.iw[0] = __uint_as_float(p0.w);
+        c.x[1] = (int32_t)p1.x >> 8; c.y[1] = (int32_t)p1.y; c.iw[1] = __uint_as_float(p1.w);
+        c.x[2] = (int32_t)p2.x >> 8; c.y[2] = (int32_t)p2.y; c.iw[2] = __uint_as_float(p2.w);
     } else {
         const ClipTri* ct = &fp.clip_tris[pr.v0 + sub];
 #pragma unroll
