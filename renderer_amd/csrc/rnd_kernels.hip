@@ -1382,8 +1382,9 @@ __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Shad
             float unx = interp(lnx, v0.uv[0], v1.uv[0], v2.uv[0]), vnx = interp(lnx, v0.uv[1], v1.uv[1], v2.uv[1]);
             float uny = interp(lny, v0.uv[0], v1.uv[0], v2.uv[0]), vny = interp(lny, v0.uv[1], v1.uv[1], v2.uv[1]);
             if (RND_PROBE(fp, 512u)) { u = 0.5f; v = 0.5f; unx = 0.5001f; vnx = 0.5f; uny = 0.5f; vny = 0.5001f; } /* every lane samples the same texels */
-            float dudx = (x & 1) ? u - unx : unx - u, dvdx = (x & 1) ? v - vnx : vnx - v;
-            float dudy = (y & 1) ? u - uny : uny - u, dvdy = (y & 1) ? v - vny : vny - v;
+            /* toward the quad neighbour, which lies on either side: the sampler squares these, so the direction
+             * does not reach the result (a difference and its negative have the same square) */
+            const float dudx = unx - u, dvdx = vnx - v, dudy = uny - u, dvdy = vny - v;
             if (fp.pass_texture >= 0) sample_texture<true>(tb, fp.pass_tex, pass_levels, u, v, dudx, dvdx, dudy, dvdy, tex);
             else sample_texture<false>(tb, fp.textures[texture], nullptr, u, v, dudx, dvdx, dudy, dvdy, tex);
         } else {
