@@ -1506,6 +1506,131 @@ __device__ __forceinline__ void raster_stream(const FrameParams& fp, const TileC
     }
 }
 
+/* The single-sample kernel's form of the same pipeline, with the data in flight held in LDS instead of registers.
+ *
+ * A thread's entry of batch b+2 and its three corners of batch b+1 are fetched by loads that write LDS directly
+ * (global_load_lds_dwordx4: per-lane source address, destination the wave's 1 KiB piece of the staging array plus
+ * 16 bytes per lane), so nothing is held in registers while the batch b is rasterised, nothing of it can be spilled,
+ * and the only waits are the two written here.  (With the loads' destinations in registers the compiler waits for
+ * the corners right where they are issued, to shift x into place, and carries the prefetched entry over the loop's
+ * edge through scratch memory, which makes every batch wait for both round trips.)  The tile's own list and the
+ * pass-wide list run through the one loop as entries 0 .. n-1 and n .. n+n_large-1. */
+struct StageArrays {
+    uint4* entry;        /* [TILE_THREADS] */
+    uint4* corner;       /* [3][TILE_THREADS] */
+};
+
+/* 16 bytes per lane from each lane's own address into the wave's piece of an LDS array (byte address lds_piece,
+ * the same for the whole wave; lane l's bytes land at lds_piece + 16 l).  Written as an assembly statement so that
+ * the compiler does not count the copy: knowing of it, it waits for every copy in flight before each LDS atomic of
+ * the rasteriser, which it cannot tell from the staging arrays.  Completion is awaited by wait_for_async_copies(). */
+__device__ __forceinline__ void async_copy16(const void* src, uint32_t lds_piece)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_piece) : "memory");
+}
+
+/* three such copies into three pieces `step` bytes apart, M0 saved and restored once */
+__device__ __forceinline__ void async_copy16x3(const void* src0, const void* src1, const void* src2, uint32_t lds_piece, uint32_t step)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src0), "v"(src1), "v"(src2), "s"(lds_piece), "s"(step) : "memory", "scc");
+}
+
+__device__ __forceinline__ uint32_t lds_byte_address(const void* p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+__device__ __forceinline__ void wait_for_async_copies() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_for_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void raster_lists_staged(const FrameParams& fp, const TileCtx& tc, const StageArrays& st, const TileEntry* list,
+                                                    uint32_t n_list, uint32_t n_large, int tx, int ty)
+{
+    const uint32_t n = n_list + n_large;
+    if (n == 0) return;
+    const uint32_t lane_slot = threadIdx.x, wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    const uint32_t entry_piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(st.entry + wave_first));
+    const uint32_t corner_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(st.corner + wave_first));
+    /* entry of a thread in the batch that starts at `base`: consecutive (coalesced loads) unless
+     * that would leave a whole wave idle; such a batch is dealt round-robin to the four waves */
+    auto entry_of = [&](uint32_t base) -> uint32_t {
+        if (base >= n) return n;
+        if (n - base > (uint32_t)(TILE_THREADS - 64)) return base + threadIdx.x < n ? base + threadIdx.x : n;
+        const uint32_t j = (threadIdx.x & 63u) * (TILE_THREADS / 64u) + (threadIdx.x >> 6);
+        return j < n - base ? base + j : n;
+    };
+    auto fetch_entry = [&](uint32_t i) {
+        const void* src = i < n_list ? (const void*)(list + i) : (const void*)&fp.large_list[i - n_list].e;
+        async_copy16(src, entry_piece);
+    };
+    /* an entry of the pass-wide list applies to a box of tiles */
+    auto applies = [&](uint32_t i) -> bool {
+        if (i < n_list) return true;
+        const uint32_t box = fp.large_list[i - n_list].box;
+        const int bx0 = box & 255u, by0 = (box >> 8) & 255u, bx1 = (box >> 16) & 255u, by1 = box >> 24;
+        return tx >= bx0 && tx <= bx1 && ty >= by0 && ty <= by1;
+    };
+    /* the three 16-byte pieces that hold a triangle's corners: its svtx records, or the head of its ClipTri */
+    auto fetch_corners = [&](const uint4& e) {
+        const uint8_t *p0, *p1, *p2;
+        if (e.w & FLAG_CLIPPED) {
+            p0 = reinterpret_cast<const uint8_t*>(&fp.clip_tris[e.x]); p1 = p0 + 16; p2 = p0 + 32;
+        } else {
+            p0 = reinterpret_cast<const uint8_t*>(&fp.svtx[e.x]); p1 = reinterpret_cast<const uint8_t*>(&fp.svtx[e.y]);
+            p2 = reinterpret_cast<const uint8_t*>(&fp.svtx[e.z]);
+        }
+        async_copy16x3(p0, p1, p2, corner_first, TILE_THREADS * 16u);
+    };
+    uint32_t flags_cur = 0, i_mid;
+    bool h_cur, h_mid;
+    {
+        const uint32_t i0 = entry_of(0);
+        if (i0 < n) fetch_entry(i0);
+        wait_for_async_copies();
+        const uint4 e = st.entry[lane_slot];
+        wait_for_lds_reads();
+        h_cur = i0 < n && applies(i0);
+        if (h_cur) fetch_corners(e);
+        flags_cur = e.w;
+        i_mid = entry_of(TILE_THREADS);
+        h_mid = i_mid < n;
+        if (h_mid) fetch_entry(i_mid);
+    }
+    for (uint32_t base = 0; base < n; base += TILE_THREADS) {
+        wait_for_async_copies(); /* the corners of this batch and the entry of the next have landed */
+        const uint4 c0 = st.corner[lane_slot], c1 = st.corner[TILE_THREADS + lane_slot], c2 = st.corner[2 * TILE_THREADS + lane_slot];
+        const uint4 e_mid = st.entry[lane_slot];
+        wait_for_lds_reads();
+        const bool h_next = h_mid && applies(i_mid);
+        if (h_next) fetch_corners(e_mid);
+        const uint32_t i_in = entry_of(base + 2u * TILE_THREADS);
+        const bool h_in = i_in < n;
+        if (h_in) fetch_entry(i_in);
+        RasterTri t;
+        t.slot = flags_cur & SLOT_MASK;
+        if (flags_cur & FLAG_CLIPPED) {
+            /* ClipTri: x[3], y[3], z[3] in its first nine words */
+            t.x[0] = (int32_t)c0.x; t.x[1] = (int32_t)c0.y; t.x[2] = (int32_t)c0.z;
+            t.y[0] = (int32_t)c0.w; t.y[1] = (int32_t)c1.x; t.y[2] = (int32_t)c1.y;
+            t.z[0] = __uint_as_float(c1.z); t.z[1] = __uint_as_float(c1.w); t.z[2] = __uint_as_float(c2.x);
+            t.payload_lo = ((flags_cur >> ENTRY_SUB_SHIFT) & 7u) | 8u;
+        } else {
+            t.x[0] = (int32_t)c0.x >> 8; t.y[0] = (int32_t)c0.y; t.z[0] = __uint_as_float(c0.z);
+            t.x[1] = (int32_t)c1.x >> 8; t.y[1] = (int32_t)c1.y; t.z[1] = __uint_as_float(c1.z);
+            t.x[2] = (int32_t)c2.x >> 8; t.y[2] = (int32_t)c2.y; t.z[2] = __uint_as_float(c2.z);
+            t.payload_lo = 0;
+        }
+        raster_batch<1>(fp, tc, h_cur, t);
+        h_cur = h_next; flags_cur = e_mid.w; h_mid = h_in; i_mid = i_in;
+    }
+}
+
 /* sRGB tables global -> LDS: one 16-byte load per thread */
 __device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables* src)
 {
@@ -1592,6 +1717,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     __shared__ unsigned long long keys[TILE_PIXELS * S];
     __shared__ ShadeTables tb;
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
+    __shared__ uint4 stage_entry[S == 1 ? TILE_THREADS : 1], stage_corner[S == 1 ? 3 * TILE_THREADS : 1];
     uint32_t tile, utx, uty;
     if (fp.shard_count == 1) {
         /* the grid covers the tiles the render area touches */
@@ -1630,15 +1756,21 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
         if (RND_PROBE(fp, 16u)) count = min(count, 256u);
         if (RND_PROBE(fp, 64u)) count = min(count, 512u);
         const TileEntry* list = fp.tile_lists + (size_t)tile * fp.tile_stride;
-        raster_stream<S>(fp, tc, count, [&](uint32_t i, TileEntry& e) -> bool { e = list[i]; return true; });
         /* the pass-wide list: primitives spanning many tiles, and spill of full tile lists */
         const uint32_t n_large = min(listed_large, fp.large_capacity);
-        raster_stream<S>(fp, tc, n_large, [&](uint32_t i, TileEntry& e) -> bool {
-            const LargeEntry le = fp.large_list[i];
-            const int bx0 = le.box & 255u, by0 = (le.box >> 8) & 255u, bx1 = (le.box >> 16) & 255u, by1 = le.box >> 24;
-            e = le.e;
-            return tx >= bx0 && tx <= bx1 && ty >= by0 && ty <= by1;
-        });
+        if constexpr (S == 1) {
+            StageArrays st;
+            st.entry = stage_entry; st.corner = stage_corner;
+            raster_lists_staged(fp, tc, st, list, count, n_large, tx, ty);
+        } else {
+            raster_stream<S>(fp, tc, count, [&](uint32_t i, TileEntry& e) -> bool { e = list[i]; return true; });
+            raster_stream<S>(fp, tc, n_large, [&](uint32_t i, TileEntry& e) -> bool {
+                const LargeEntry le = fp.large_list[i];
+                const int bx0 = le.box & 255u, by0 = (le.box >> 8) & 255u, bx1 = (le.box >> 16) & 255u, by1 = le.box >> 24;
+                e = le.e;
+                return tx >= bx0 && tx <= bx1 && ty >= by0 && ty <= by1;
+            });
+        }
     }
     RND_STAMP(fp, stamp, 1); /* rasterisation */
     if (blockIdx.x == 0 && threadIdx.x == 0) {
