@@ -217,12 +217,12 @@ __device__ __forceinline__ float lane_value(float v, int lane)
  * shader uses mvp alone (dummy.vert.glsl:22).  Lane k < 16 computes element k of the first product,
  * lane 16 + k element k of the second, each as the same four-term multiply-add chain a scalar
  * implementation runs; the results are then broadcast. */
-__device__ __forceinline__ float wave_matrix_element(const UniformPatch& up, const DrawStatic& d)
+__device__ __forceinline__ float wave_matrix_element(const UniformPatch& up, const DrawStatic& d, int shader, const float* ubo)
 {
     const uint32_t lane = lane_id();
     const uint32_t k = lane & 15u, row = k & 3u, col = k >> 2;
-    if (d.shader == 0) return uniform_read(up, d.ubo + 64 + k);
-    const float* a = d.ubo + ((lane & 16u) ? 48 : 64); /* model : mvp */
+    if (shader == 0) return uniform_read(up, ubo + 64 + k);
+    const float* a = ubo + ((lane & 16u) ? 48 : 64); /* model : mvp */
     const float* b = d.push + 4 + col * 4;
     float acc = uniform_read(up, a + 0 * 4 + row) * b[0];
     acc = fma32(uniform_read(up, a + 1 * 4 + row), b[1], acc);
@@ -239,9 +239,9 @@ __device__ __forceinline__ void wave_clip_matrix(float element, float* clip_m)
 }
 
 /* the normal matrix, from lanes 16..26 */
-__device__ __forceinline__ void wave_normal_matrix(const DrawStatic& d, float element, float* nrm_m)
+__device__ __forceinline__ void wave_normal_matrix(int shader, float element, float* nrm_m)
 {
-    if (d.shader == 0) {
+    if (shader == 0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) nrm_m[i] = 0.0f;
     } else {
@@ -303,14 +303,14 @@ __global__ __launch_bounds__(256) void k_draws(VertexArgs args)
     if (draw >= fp.n_draws) return;
     const DrawStatic& d = fp.draws[draw];
     float m[16], nm[9];
-    const float mine = wave_matrix_element(args.up, d);
+    const float mine = wave_matrix_element(args.up, d, d.shader, d.ubo);
     wave_clip_matrix(mine, m);
     bool outside = d.vert_count == 0u;
     if (d.has_bounds != 0u && fp.cull_draws != 0u) outside = outside || draw_is_outside(fp, d, m);
     DrawDerived& out = fp.derived[draw];
     if (lane_id() == 0) out.visible = outside ? 0u : 1u;
     if (outside) return;
-    wave_normal_matrix(d, mine, nm);
+    wave_normal_matrix(d.shader, mine, nm);
     if (lane_id() < 16u) out.clip_m[lane_id()] = mine;
 #pragma unroll
     for (int i = 0; i < 9; ++i) if (lane_id() == (uint32_t)i) out.nrm_m[i] = nm[i];
@@ -323,24 +323,36 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     const FrameParams& fp = args.fp;
     const UniformPatch& up = args.up;
     RND_KERNEL_BEGIN(fp, 0);
-    /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel */
-    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
     const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= fp.n_vchunks) return;
     Chunk c = {0u, chunk * 64u}; /* what the chunk table of a one-draw pass holds */
     if (!fp.direct_index) c = fp.vchunks[chunk];
-    const DrawStatic& d = fp.draws[c.draw];
+    /* The chunk is the same for the whole wave, and said so; and the draw's record is copied here, before the kernel's
+     * first store.  Both are needed for the record to be read with scalar loads, all at once: a field read after a
+     * store that might have changed it is read with a vector load of its own, and the kernel began with six of those in
+     * a row, each waiting for the one before. */
+    c.draw = wave_uniform(c.draw); c.first = wave_uniform(c.first);
+    const DrawStatic& dm = fp.draws[c.draw]; /* the record in memory: what is indexed per lane (push constants, box) */
+    struct {
+        const uint8_t* vb; const float* ubo; uint32_t stride; int32_t off_pos, off_nrm, off_uv; int32_t shader;
+        uint32_t vert_count, svtx_base, has_bounds;
+    } const d = {dm.vb, dm.ubo, dm.stride, dm.off_pos, dm.off_nrm, dm.off_uv, dm.shader, dm.vert_count, dm.svtx_base, dm.has_bounds};
+    uint32_t visible = 1u;
+    if constexpr (PREPARED) visible = fp.derived[c.draw].visible;
+    /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel
+     * (the first three threads of the grid belong to chunk 0, which every launch has) */
+    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
     float m[16], nm[9], mine = 0.0f;
-    if constexpr (PREPARED) {
-        if (!fp.derived[c.draw].visible) return;
-    }
+    if (!visible) return;
     const bool cullable = !PREPARED && d.has_bounds != 0u && fp.cull_draws != 0u;
-    if (cullable) {
-        /* a draw with a box is tested before anything of it is fetched: a culled one costs its waves
-         * the matrices and nothing else, and setup skips its primitives */
-        mine = wave_matrix_element(up, d);
+    /* A draw with a box is tested before anything of it is fetched: a culled one costs its waves the matrices
+     * and nothing else, and setup skips its primitives.  Not so the one draw of a one-draw pass, which is what
+     * the pass is there to render: its waves request their vertices first and test under that latency. */
+    const bool test_first = cullable && !fp.direct_index;
+    if (test_first) {
+        mine = wave_matrix_element(up, dm, d.shader, d.ubo);
         wave_clip_matrix(mine, m);
-        const bool outside = draw_is_outside(fp, d, m);
+        const bool outside = draw_is_outside(fp, dm, m);
         if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = outside ? 0u : 1u;
         if (outside) return;
     }
@@ -384,12 +396,14 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 #pragma unroll
         for (int i = 0; i < 9; ++i) nm[i] = dd.nrm_m[i];
     } else {
-        if (!cullable) {
-            mine = wave_matrix_element(up, d);
+        if (!test_first) {
+            mine = wave_matrix_element(up, dm, d.shader, d.ubo);
             wave_clip_matrix(mine, m);
-            if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = 1u;
+            const bool outside = cullable && draw_is_outside(fp, dm, m);
+            if (c.first == 0 && lane_id() == 0) fp.derived[c.draw].visible = outside ? 0u : 1u;
+            if (outside) return;
         }
-        wave_normal_matrix(d, mine, nm);
+        wave_normal_matrix(d.shader, mine, nm);
         if (c.first == 0 && lane_id() < 16u) fp.derived[c.draw].clip_m[lane_id()] = mine;
     }
     if (!live) return;
@@ -586,6 +600,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
     const uint32_t lane = lane_id();
     const uint32_t tri = c.first + lane;
     const uint32_t slot = chunk * 64u + lane;
+    const uint32_t svtx_base = d.svtx_base; /* read before the record below is stored: after it the compiler reads the draw's record again, per lane */
     bool valid = false, needs_clip = false;
     TileEntry e = {0, 0, 0, slot};
     uint32_t box = BBOX_CULLED;
@@ -603,14 +618,14 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
             if (setup_tri(t, d.cull_mode, d.front_face) && pixel_box(fp, t, x0, y0, x1, y1)) {
                 valid = true;
                 box = pack_bbox(x0 >> TILE_SHIFT, y0 / TILE_H, x1 >> TILE_SHIFT, y1 / TILE_H);
-                const uint32_t v0 = d.svtx_base + pf.idx[0], v1 = d.svtx_base + pf.idx[1], v2 = d.svtx_base + pf.idx[2];
+                const uint32_t v0 = svtx_base + pf.idx[0], v1 = svtx_base + pf.idx[1], v2 = svtx_base + pf.idx[2];
                 /* what shading needs, in the primitive's own corner order */
                 PrimRec pr = {v0, v1, v2, c.draw};
                 if (!fp.direct_index) fp.prim_rec[slot] = pr;
                 /* what rasterisation needs: corners ordered for positive area */
-                e.a = d.svtx_base + pf.idx[t.corner[0]];
-                e.b = d.svtx_base + pf.idx[t.corner[1]];
-                e.c = d.svtx_base + pf.idx[t.corner[2]];
+                e.a = svtx_base + pf.idx[t.corner[0]];
+                e.b = svtx_base + pf.idx[t.corner[1]];
+                e.c = svtx_base + pf.idx[t.corner[2]];
             }
         }
     }
