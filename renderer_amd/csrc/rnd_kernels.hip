@@ -1646,13 +1646,20 @@ __device__ __forceinline__ void raster_lists_staged(const FrameParams& fp, const
     }
 }
 
-/* sRGB tables global -> LDS: one 16-byte load per thread */
+/* sRGB tables global -> LDS, as copies that write LDS directly: a wave moves 1 KiB per instruction and holds no
+ * register for it; the copies run under whatever the caller does next and are awaited (wait_for_async_copies, then
+ * the workgroup's barrier) before the tables are read */
 __device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables* src)
 {
     static_assert(sizeof(ShadeTables) % 16 == 0, "tables are staged in 16-byte pieces");
-    const uint4* g = reinterpret_cast<const uint4*>(src);
-    uint4* l = reinterpret_cast<uint4*>(&tb);
-    for (uint32_t i = threadIdx.x; i < sizeof(ShadeTables) / 16; i += blockDim.x) l[i] = g[i];
+    constexpr uint32_t PIECES = sizeof(ShadeTables) / 16;
+    const uint32_t lds_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(&tb));
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    const uint8_t* g = reinterpret_cast<const uint8_t*>(src);
+    for (uint32_t first = wave_first; first < PIECES; first += blockDim.x) { /* the same for the whole wave */
+        const uint32_t i = first + (threadIdx.x & 63u);
+        if (i < PIECES) async_copy16(g + (size_t)i * 16u, lds_first + first * 16u);
+    }
 }
 
 constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* owner word of a sample no fragment covers; otherwise slot | fan << 28 | clipped << 31 */
@@ -1762,6 +1769,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
     for (uint32_t i = threadIdx.x; i < TILE_PIXELS * S; i += TILE_THREADS) keys[i] = clear_key;
+    wait_for_async_copies(); /* the tables */
     __syncthreads();
     RND_STAMP(fp, stamp, 0); /* prologue */
 
@@ -1825,6 +1833,7 @@ __global__ __launch_bounds__(256) void k_mip(const uint8_t* src, uint32_t sw, ui
 {
     __shared__ ShadeTables tb;
     stage_tables(tb, tables);
+    wait_for_async_copies();
     __syncthreads();
     const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
     const size_t total = (size_t)dw * dh;
