@@ -1,9 +1,9 @@
 set -e
-mkdir -p gpurun_out/r02c
-timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/r02c/tests.log 2>&1; tail -2 gpurun_out/r02c/tests.log
-timeout -k 10 200 python bench.py > gpurun_out/r02c/bench.json 2> gpurun_out/r02c/bench.err; cat gpurun_out/r02c/bench.json
-for c in 0 2 3 4; do timeout -k 10 200 python bench.py --config $c --no-cpu >> gpurun_out/r02c/bench_other_configs.jsonl 2>> gpurun_out/r02c/bench.err; done
-for c in 0 1 2; do timeout -k 10 200 python bench.py --config $c --samples 4 --no-cpu >> gpurun_out/r02c/bench_4_samples.jsonl 2>> gpurun_out/r02c/bench.err; done
-bash tools/collect_profiles.sh r02c 1
-bash tools/collect_profiles.sh r02c_c2 2
-bash tools/collect_profiles.sh r02c_c0 0
+mkdir -p gpurun_out/r02d
+timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/r02d/tests.log 2>&1; tail -2 gpurun_out/r02d/tests.log
+timeout -k 10 200 python bench.py > gpurun_out/r02d/bench.json 2> gpurun_out/r02d/bench.err; cat gpurun_out/r02d/bench.json
+for c in 0 2 3 4; do timeout -k 10 200 python bench.py --config $c --no-cpu >> gpurun_out/r02d/bench_other_configs.jsonl 2>> gpurun_out/r02d/bench.err; done
+for c in 0 1 2; do timeout -k 10 200 python bench.py --config $c --samples 4 --no-cpu >> gpurun_out/r02d/bench_4_samples.jsonl 2>> gpurun_out/r02d/bench.err; done
+bash tools/collect_profiles.sh r02d 1
+bash tools/collect_profiles.sh r02d_c2 2
+bash tools/collect_profiles.sh r02d_c0 0
