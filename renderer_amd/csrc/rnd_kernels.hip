@@ -662,6 +662,7 @@ struct TileCtx {
     int px0, py0;           /* first pixel of the tile */
     int rx0, ry0, rx1, ry1; /* inclusive pixel rectangle: tile ∩ clamp */
     unsigned long long* keys;
+    signed char* wave_row;  /* 64 bytes of LDS of this wave's own */
 };
 
 /* A triangle as the rasteriser uses it: corners ordered for positive area */
@@ -919,6 +920,21 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
     return true;
 }
 
+/* Scans over the wave by data-parallel-primitive moves (row shifts inside each 16-lane row, then the rows' last
+ * lanes broadcast to the rows after them): six vector instructions, where shuffles through the LDS crossbar take a
+ * round trip per step. */
+template <typename Op>
+__device__ __forceinline__ int wave_inclusive_scan(int v, int identity, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 into rows 1 and 3 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
 /* Who walks a triangle's box.
  *
  * A lane walking its own box costs the wave as many steps as the largest box among its lanes, so it
@@ -941,27 +957,23 @@ __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileC
     const int w = x1 - x0 + 1;
     const int area = active ? w * (y1 - y0 + 1) : 0;
     const int n = (area + CHUNK_PIXELS - 1) / CHUNK_PIXELS;
-    int incl = n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
+    const int incl = wave_inclusive_scan(n, 0, [](int a, int b) { return a + b; });
     const int excl = incl - n;
-    const int total = __shfl(incl, 63);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
     WalkSetup mine;
     if constexpr (S == 1) mine.init(fp, tc, t, x0, y0, active ? w : 1, area);
     for (int base = 0; base < total; base += 64) {
         const int c = base + lane;
-        /* owner: the last lane whose first chunk number is not above c (lanes without chunks share
-         * their successor's number and lose to it) */
-        int o = 0;
-#pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const int cand = o + step;
-            const int first = __shfl(excl, cand & 63);
-            if (cand < 64 && first <= c) o = cand;
-        }
+        /* owner of chunk c: the last lane that has chunks and whose first chunk number is not above c.  Every such lane
+         * whose first chunk falls in this round writes its number into the wave's row of LDS at that chunk's place; a
+         * running maximum over the row, started from the last lane whose first chunk lies before the round, gives every
+         * place its owner. */
+        volatile signed char* row = tc.wave_row; /* lanes talk to each other through it: every access is to happen as written */
+        row[lane] = -1;
+        if (n > 0 && excl >= base && excl < base + 64) row[excl - base] = (signed char)lane;
+        const unsigned long long before = __ballot(n > 0 && excl <= base);
+        const int carried = before ? 63 - __builtin_clzll(before) : 0;
+        const int o = max(wave_inclusive_scan((int)row[lane], -1, [](int a, int b) { return max(a, b); }), carried);
         if constexpr (S == 1) {
             const WalkSetup u = mine.from_lane(o);
             const int ofirst = __shfl(excl, o);
@@ -1740,6 +1752,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     __shared__ ShadeTables tb;
     __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
     __shared__ uint4 stage_entry[S == 1 ? TILE_THREADS : 1], stage_corner[S == 1 ? 3 * TILE_THREADS : 1];
+    __shared__ signed char wave_rows[TILE_THREADS];
     uint32_t tile, utx, uty;
     if (fp.shard_count == 1) {
         /* the grid covers the tiles the render area touches */
@@ -1757,6 +1770,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     tc.rx0 = max(tc.px0, fp.clamp_x0); tc.ry0 = max(tc.py0, fp.clamp_y0);
     tc.rx1 = min(tc.px0 + TILE_W - 1, fp.clamp_x1); tc.ry1 = min(tc.py0 + TILE_H - 1, fp.clamp_y1);
     tc.keys = keys;
+    tc.wave_row = wave_rows + (threadIdx.x & ~63u);
     RND_STAMP_START(stamp);
 
     /* the length of the tile's list is asked for first: its round trip runs under the staging of
