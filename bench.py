@@ -518,7 +518,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=600)
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--samples", type=int, choices=[1, 4], default=1,
                     help="samples per pixel (4: what test_app renders with, dummy_obj_viewer_app.cpp:319; resolved in linear light)")

@@ -297,7 +297,10 @@ void launch_index_range(const IndexRangeJob* jobs, uint32_t* out_max, uint32_t n
 void launch_bounds(const BoundsJob* jobs, uint32_t* out_min_max, uint32_t n_jobs, hipStream_t s);
 void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s); /* with the per-draw kernel first when the pass has many draws */
 void launch_setup(const FrameParams& fp, hipStream_t s);
-void launch_tile(const FrameParams& fp, hipStream_t s);
+/* lds_pad: bytes of LDS a tile workgroup claims beyond what it uses (0, or TILE_LDS_PAD_FOUR so that four workgroups
+ * fit a CU instead of five; the single-sample kernel only) */
+constexpr uint32_t TILE_LDS_PAD_FOUR = 2048;
+void launch_tile(const FrameParams& fp, hipStream_t s, uint32_t lds_pad = 0);
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
                 const struct ShadeTables* tables, hipStream_t s);
 

@@ -1936,7 +1936,7 @@ void launch_setup(const FrameParams& fp, hipStream_t s)
     hipLaunchKernelGGL(k_setup, dim3(blocks), dim3(256), 0, s, fp);
 }
 
-void launch_tile(const FrameParams& fp, hipStream_t s)
+void launch_tile(const FrameParams& fp, hipStream_t s, uint32_t lds_pad)
 {
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     const uint32_t mine = n_tiles > fp.shard_index ? (n_tiles - fp.shard_index + fp.shard_count - 1) / fp.shard_count : 0;
@@ -1945,7 +1945,7 @@ void launch_tile(const FrameParams& fp, hipStream_t s)
     const uint32_t grid = fp.shard_count == 1 ? rows_of_eight_grid(fp.grid_w, fp.grid_h) : mine;
     const uint32_t magic = rows_of_eight_magic(fp.shard_count == 1 ? fp.grid_w : fp.tiles_x);
     if (fp.samples == 4) hipLaunchKernelGGL(k_tile<4>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
-    else hipLaunchKernelGGL(k_tile<1>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
+    else hipLaunchKernelGGL(k_tile<1>, dim3(grid), dim3(TILE_THREADS), (size_t)lds_pad, s, fp, magic);
 }
 
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,

@@ -639,3 +639,44 @@ def test_small_write_into_a_shared_uniform_vertex_buffer_reaches_memory(device, 
     sc.vbs[0] = moved
     oc, od, _ = oracle.render_scene(sc, threads=4)
     assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
+@pytest.mark.parametrize("workgroups", ["4", "5", "measured"])
+def test_tile_workgroups_per_cu_do_not_change_the_frame(oracle, workgroups, monkeypatch):
+    """How many tile workgroups share a CU (RND_TILE_WORKGROUPS=4 / 5, or measured by the device over its first few
+    hundred submits) changes when a frame is finished, never what is in it: 500 frames rotate through two command
+    buffers -- enough for a measuring device to pass through every stretch of its measurement -- and the last two
+    are compared with the oracle."""
+    from renderer_amd import api
+    if workgroups == "measured":
+        monkeypatch.delenv("RND_TILE_WORKGROUPS", raising=False)
+    else:
+        monkeypatch.setenv("RND_TILE_WORKGROUPS", workgroups)
+    dev = api.Device(0)  # the setting is read when a device is created
+    try:
+        sc = scenes.config0(320, 180, tex_size=64, segments=48, rings=24)
+        model = np.asarray(sc.ubos[0][48:64], dtype=np.float32).reshape(4, 4)
+        n_frames = 500
+        ubos = []
+        for i in range(4):
+            cam = hm.Camera()
+            cam.eye_position = np.array([0.2 * np.sin(0.7 * i), 0.05 * i, -2.0 - 0.04 * i], dtype=np.float32)
+            ubos.append(hm.global_ubo(cam, model, sc.width, sc.height))
+        r = SceneRunner(sc, dev, frames_in_flight=2)
+        try:
+            owner = {}
+            for i in range(n_frames):
+                r.set_ubo(0, ubos[i % 4])
+                owner[r.submit()] = i
+            dev.wait_idle()
+            got = {img: r.targets[img].read() for img in owner}
+        finally:
+            r.destroy()
+        assert len(owner) == 2
+        for img, frame in owner.items():
+            sc.ubos[0] = ubos[frame % 4]
+            oc, od, _ = oracle.render_scene(sc, threads=4)
+            assert np.array_equal(got[img][1], od), "image %d (frame %d): depth differs" % (img, frame)
+            assert np.array_equal(got[img][0], oc), "image %d (frame %d): colour differs" % (img, frame)
+    finally:
+        dev.destroy()
