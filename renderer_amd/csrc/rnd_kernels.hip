@@ -295,6 +295,9 @@ __device__ __forceinline__ bool draw_is_outside(const FrameParams& fp, const Dra
  * two matrices and the verdict on the draw's box.  The vertex kernel then starts from three scalar loads, and
  * a culled draw costs each of its waves one of them. */
 constexpr uint32_t PER_DRAW_KERNEL_MIN_DRAWS = 256;
+/* ... and a pass of few draws with many vertices: every vertex wave builds its draw's matrices again (two thirds of
+ * such a wave's vector instructions), which for some thousand waves is more than the extra launch costs */
+constexpr uint32_t PER_DRAW_KERNEL_MIN_WAVES = 2048;
 
 __global__ __launch_bounds__(256) void k_draws(VertexArgs args)
 {
@@ -1920,7 +1923,7 @@ void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t
     if (!blocks) return;
     VertexArgs args;
     args.fp = fp; args.up = patch;
-    if (fp.n_draws >= PER_DRAW_KERNEL_MIN_DRAWS) {
+    if (fp.n_draws >= PER_DRAW_KERNEL_MIN_DRAWS || fp.n_vchunks >= PER_DRAW_KERNEL_MIN_WAVES) {
         hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + 3) / 4), dim3(256), 0, s, args);
         hipLaunchKernelGGL(k_vertex<true>, dim3(blocks), dim3(256), 0, s, args);
     } else {
