@@ -486,13 +486,25 @@ __device__ __forceinline__ void bin_wave(const FrameParams& fp, bool valid, cons
     int n = valid ? w * h : 0;
     const bool large = n > MAX_TILES_PER_PRIM;
     if (large) n = 0;
+    /* tile (row, col) of the box, if this device renders it (one device renders every tile: no remainder to take) */
+    auto tile_at = [&](int row, int col) -> int {
+        const int t = (ty0 + row) * (int)fp.tiles_x + tx0 + col;
+        if (fp.shard_count != 1u && (uint32_t)t % fp.shard_count != fp.shard_index) return -1;
+        return t;
+    };
     auto tile_of = [&](int k) -> int {
         if (k >= n) return -1;
-        const int t = (ty0 + k / w) * (int)fp.tiles_x + tx0 + k % w;
-        return ((uint32_t)t % fp.shard_count == fp.shard_index) ? t : -1;
+        return tile_at(k / w, k % w);
+    };
+    /* the box's first four tiles in row order without the division: their row is how many multiples of the
+     * width they have passed */
+    auto tile_of_first = [&](int k) -> int {
+        if (k >= n) return -1;
+        const int row = (k >= w ? 1 : 0) + (k >= 2 * w ? 1 : 0) + (k >= 3 * w ? 1 : 0);
+        return tile_at(row, k - row * w);
     };
     /* group the wave's first tiles */
-    const int t0 = tile_of(0);
+    const int t0 = tile_of_first(0);
     uint64_t pending = __ballot(t0 >= 0);
     int leader = -1;
     uint32_t rank = 0, group = 0;
@@ -509,7 +521,7 @@ __device__ __forceinline__ void bin_wave(const FrameParams& fp, bool valid, cons
     }
     /* issue every atomic before using any result */
     uint32_t base0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    const int t1 = tile_of(1), t2 = tile_of(2), t3 = tile_of(3);
+    const int t1 = tile_of_first(1), t2 = tile_of_first(2), t3 = tile_of_first(3);
     if ((int)lane == leader) base0 = atomicAdd(&fp.tile_count[(size_t)t0 * TILE_COUNT_STRIDE], group);
     if (t1 >= 0) p1 = atomicAdd(&fp.tile_count[(size_t)t1 * TILE_COUNT_STRIDE], 1u);
     if (t2 >= 0) p2 = atomicAdd(&fp.tile_count[(size_t)t2 * TILE_COUNT_STRIDE], 1u);
