@@ -523,7 +523,7 @@ def main():
     ap.add_argument("--samples", type=int, choices=[1, 4], default=1,
                     help="samples per pixel (4: what test_app renders with, dummy_obj_viewer_app.cpp:319; resolved in linear light)")
     ap.add_argument("--mode", choices=["views", "tiles", "bands"], default="views")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="command buffers / targets the frames rotate through (the reference's swapchain image count)")
     ap.add_argument("--one-shard-of", type=int, default=1, metavar="N",
                     help="single-GPU rehearsal of the tiles mode (or, with --mode bands, the bands mode): render only what "
