@@ -106,26 +106,12 @@ struct rnd_device_t {
     float stage_ms[RND_STAGE_COUNT] = {};
     bool stage_valid = false;
 
-    /* How many tile workgroups share a CU, chosen by what the device measures.
-     *
-     * Five single-sample tile workgroups fill a CU's registers; the vertex and setup waves of the next frame in flight
-     * then start only as tile waves retire.  With four (a tile workgroup made to claim 2 KB more LDS) those waves run
-     * beside the tile kernel: frames whose geometry kernels are a large part of the frame come out ~4 % sooner, frames
-     * that are nearly all tile kernel ~4-9 % later.  Which it is cannot be told when a command buffer is recorded, so
-     * the device times both: after a settling stretch, WINDOW submits with five, WINDOW with four and WINDOW with five
-     * again, each between two events (the first SKIP submits of a stretch not counted; the stretch with four is compared
-     * with the mean of the two around it, so that clocks still ramping do not favour whichever comes later); four is
-     * kept for HOLD submits if it was shorter by more than the stretches' noise, else five, then the question is asked
-     * again.  Both settings render the same bits.  RND_TILE_WORKGROUPS=4 or 5 pins the setting. */
-    struct OccupancyTuner {
-        static constexpr uint32_t SETTLE = 64, SKIP = 8, WINDOW = 128, HOLD = 16384;
-        enum Phase { SETTLING, TIMING_FIVE, TIMING_FOUR, TIMING_FIVE_AGAIN, WAITING, HOLDING } phase = SETTLING;
-        uint32_t count = 0;
-        int pinned = -1;          /* 0 five, 1 four, -1 measured */
-        int chosen = 0;
-        hipEvent_t ev[6] = {};    /* start and end of the three stretches */
-        bool have_events = false;
-    } tuner;
+    /* How many single-sample tile workgroups share a CU.  Five fill a CU's registers; with four (a tile workgroup made
+     * to claim 2 KB more LDS) the vertex and setup waves of the next frame find room beside the tile kernel instead of
+     * starting as tile waves retire.  Five is the setting: measured the same or faster on every benchmark workload at
+     * one to four frames in flight, once each command buffer had a hardware queue of its own.  RND_TILE_WORKGROUPS=4
+     * chooses four; both render the same bits. */
+    bool four_tile_workgroups = false;
 };
 
 struct rnd_buffer_t {
@@ -564,8 +550,6 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         dev->status_dev = static_cast<uint32_t*>(dp);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&dev->order_ev, hipEventDisableTiming);
-    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&dev->tuner.ev[i]);
-    dev->tuner.have_events = e == hipSuccess;
     /* The runtime keeps one pool of hardware queues per stream priority (GPU_MAX_HW_QUEUES of them each, 4 unless the
      * environment says otherwise) and lets streams share a queue once a pool is used up; two command buffers on one
      * queue run one after the other instead of side by side (measured: three frames in flight 53 us per frame with
@@ -580,7 +564,7 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         const char* pr = getenv("RND_STREAM_PRIORITY");
         dev->cmd_stream_priority = !pr || !strcmp(pr, "low") ? least : !strcmp(pr, "high") ? greatest : 0;
     }
-    if (const char* pin = getenv("RND_TILE_WORKGROUPS")) dev->tuner.pinned = atoi(pin) == 4 ? 1 : (atoi(pin) == 5 ? 0 : -1);
+    if (const char* wg = getenv("RND_TILE_WORKGROUPS")) dev->four_tile_workgroups = atoi(wg) == 4;
     /* every GPU holds its own copy of the static scratch array at its own address: asked for once per device, here,
      * with that device current */
     if (e == hipSuccess) { void* sp = nullptr; e = noalloc_scratch_address(&sp); dev->scratch = static_cast<uint8_t*>(sp); }
@@ -599,7 +583,6 @@ int rnd_device_destroy(rnd_device dev)
     (void)hipSetDevice(dev->ordinal);
     (void)sync_all(dev);
     if (dev->order_ev) (void)hipEventDestroy(dev->order_ev);
-    for (int i = 0; i < 6; ++i) if (dev->tuner.ev[i]) (void)hipEventDestroy(dev->tuner.ev[i]);
     if (dev->tables) (void)hipFree(dev->tables);
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) if (dev->ev[i]) (void)hipEventDestroy(dev->ev[i]);
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) if (dev->stage_ev[i]) (void)hipEventDestroy(dev->stage_ev[i]);
@@ -1366,58 +1349,6 @@ int rnd_cmd_destroy(rnd_cmd cmd)
 
 /* ------------------------------------------------------------------ submit */
 
-/* One submit of a single-sample pass: which setting its tile kernel runs with, and the events of the timing stretches
- * (recorded after the frame's kernels on the frame's stream, hence two calls: before and after the launches). */
-static uint32_t tuner_setting(rnd_device dev)
-{
-    rnd_device_t::OccupancyTuner& t = dev->tuner;
-    if (t.pinned >= 0) return (uint32_t)t.pinned;
-    if (!t.have_events) return 0u;
-    switch (t.phase) {
-    case rnd_device_t::OccupancyTuner::TIMING_FOUR: return 1u;
-    case rnd_device_t::OccupancyTuner::HOLDING: return (uint32_t)t.chosen;
-    default: return 0u;
-    }
-}
-
-static void tuner_after_submit(rnd_device dev, hipStream_t s)
-{
-    typedef rnd_device_t::OccupancyTuner T;
-    T& t = dev->tuner;
-    if (t.pinned >= 0 || !t.have_events) return;
-    ++t.count;
-    switch (t.phase) {
-    case T::SETTLING:
-        if (t.count >= T::SETTLE) { t.phase = T::TIMING_FIVE; t.count = 0; }
-        break;
-    case T::TIMING_FIVE:
-        if (t.count == T::SKIP) (void)hipEventRecord(t.ev[0], s);
-        if (t.count == T::SKIP + T::WINDOW) { (void)hipEventRecord(t.ev[1], s); t.phase = T::TIMING_FOUR; t.count = 0; }
-        break;
-    case T::TIMING_FOUR:
-        if (t.count == T::SKIP) (void)hipEventRecord(t.ev[2], s);
-        if (t.count == T::SKIP + T::WINDOW) { (void)hipEventRecord(t.ev[3], s); t.phase = T::TIMING_FIVE_AGAIN; t.count = 0; }
-        break;
-    case T::TIMING_FIVE_AGAIN:
-        if (t.count == T::SKIP) (void)hipEventRecord(t.ev[4], s);
-        if (t.count == T::SKIP + T::WINDOW) { (void)hipEventRecord(t.ev[5], s); t.phase = T::WAITING; t.count = 0; }
-        break;
-    case T::WAITING:
-        if (hipEventQuery(t.ev[5]) == hipSuccess) {
-            float five = 0.0f, four = 0.0f, again = 0.0f;
-            if (hipEventElapsedTime(&five, t.ev[0], t.ev[1]) == hipSuccess && hipEventElapsedTime(&four, t.ev[2], t.ev[3]) == hipSuccess &&
-                hipEventElapsedTime(&again, t.ev[4], t.ev[5]) == hipSuccess)
-                t.chosen = four < 0.975f * 0.5f * (five + again) ? 1 : 0; /* four only for a gain beyond the stretches' noise */
-            t.phase = T::HOLDING; t.count = 0;
-        }
-        break;
-    case T::HOLDING:
-        if (t.count >= T::HOLD) { t.phase = T::TIMING_FIVE; t.count = 0; }
-        break;
-    }
-}
-
-
 int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
 {
     if (!dev || !cmd) return fail(RND_ERROR_INVALID_ARGUMENT, "submit: bad arguments");
@@ -1453,10 +1384,7 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_SETUP], s));
     launch_setup(fp, s);
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_TILE], s));
-    /* frames of command buffers that share the caller's one stream do not overlap: nothing to tune */
-    const bool tuned = cmd->own_stream && fp.samples == 1 && !prof;
-    launch_tile(fp, s, tuned && tuner_setting(dev) ? TILE_LDS_PAD_FOUR : 0u);
-    if (tuned) tuner_after_submit(dev, s);
+    launch_tile(fp, s, dev->four_tile_workgroups && fp.samples == 1 ? TILE_LDS_PAD_FOUR : 0u);
     if (prof) { HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_COUNT], s)); dev->stage_valid = true; }
     HIP_TRY(hipGetLastError());
     if (cmd->own_stream) {

@@ -641,28 +641,26 @@ def test_small_write_into_a_shared_uniform_vertex_buffer_reaches_memory(device, 
     assert np.array_equal(depth, od) and np.array_equal(color, oc)
 
 
-@pytest.mark.parametrize("workgroups", ["4", "5", "measured"])
-def test_tile_workgroups_per_cu_do_not_change_the_frame(oracle, workgroups, monkeypatch):
-    """How many tile workgroups share a CU (RND_TILE_WORKGROUPS=4 / 5, or measured by the device over its first few
-    hundred submits) changes when a frame is finished, never what is in it: 500 frames rotate through two command
-    buffers -- enough for a measuring device to pass through every stretch of its measurement -- and the last two
-    are compared with the oracle."""
+@pytest.mark.parametrize("setting", ["RND_TILE_WORKGROUPS=4", "RND_TILE_WORKGROUPS=5", "RND_STREAM_PRIORITY=high",
+                                     "RND_STREAM_PRIORITY=normal", "RND_STREAM_PRIORITY=low"])
+def test_scheduling_settings_do_not_change_the_frame(oracle, setting, monkeypatch):
+    """How many tile workgroups share a CU (RND_TILE_WORKGROUPS=4, otherwise five) and which pool of hardware queues
+    the command buffers' streams come from (RND_STREAM_PRIORITY) change when a frame is finished, never what is in
+    it: 60 frames rotate through three command buffers, each on a stream of its own, and the last three are compared
+    with the oracle."""
     from renderer_amd import api
-    if workgroups == "measured":
-        monkeypatch.delenv("RND_TILE_WORKGROUPS", raising=False)
-    else:
-        monkeypatch.setenv("RND_TILE_WORKGROUPS", workgroups)
-    dev = api.Device(0)  # the setting is read when a device is created
+    monkeypatch.setenv(*setting.split("="))
+    dev = api.Device(0)  # the settings are read when a device is created
     try:
         sc = scenes.config0(320, 180, tex_size=64, segments=48, rings=24)
         model = np.asarray(sc.ubos[0][48:64], dtype=np.float32).reshape(4, 4)
-        n_frames = 500
+        n_frames = 60
         ubos = []
         for i in range(4):
             cam = hm.Camera()
             cam.eye_position = np.array([0.2 * np.sin(0.7 * i), 0.05 * i, -2.0 - 0.04 * i], dtype=np.float32)
             ubos.append(hm.global_ubo(cam, model, sc.width, sc.height))
-        r = SceneRunner(sc, dev, frames_in_flight=2)
+        r = SceneRunner(sc, dev, frames_in_flight=3)
         try:
             owner = {}
             for i in range(n_frames):
@@ -672,7 +670,7 @@ def test_tile_workgroups_per_cu_do_not_change_the_frame(oracle, workgroups, monk
             got = {img: r.targets[img].read() for img in owner}
         finally:
             r.destroy()
-        assert len(owner) == 2
+        assert len(owner) == 3
         for img, frame in owner.items():
             sc.ubos[0] = ubos[frame % 4]
             oc, od, _ = oracle.render_scene(sc, threads=4)
