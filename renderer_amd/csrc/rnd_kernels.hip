@@ -1071,13 +1071,12 @@ struct Varyings { float light; float uv[2]; };
 /* Vertex-shader outputs other than the position, as the vertex kernel left them */
 __device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vtx, int shader, Varyings& out)
 {
-    /* three adjacent words: one 12-byte load, addressed as the array's (uniform) base plus a 32-bit byte offset --
-     * the records of a pass stay far below 4 GB -- which the load instruction takes as it is; a 64-bit address per lane
-     * costs a quarter-rate 64-bit multiply-add each */
+    /* three adjacent words: one 12-byte load.  The address is 64 bits per lane: draws that index one vertex buffer
+     * from its start each transform it up to their largest index, and a pass of some hundred such draws holds more
+     * than 4 GB of records */
     typedef float Triple __attribute__((ext_vector_type(3), aligned(4)));
     typedef const __attribute__((address_space(1))) Triple* GlobalTriple;
-    const uint32_t offset = (vtx << 3) + (vtx << 2);
-    const Triple a = *(GlobalTriple)(reinterpret_cast<const uint8_t*>(fp.svary) + offset);
+    const Triple a = *(GlobalTriple)&fp.svary[vtx];
     out.light = a.x;
     out.uv[0] = a.y;
     out.uv[1] = shader == 0 ? 1.0f - a.z : a.z; /* dummy.vert.glsl:25 flips v */
@@ -1519,9 +1518,7 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
          * clipped branch's reads into nine single-word loads through selected pointers */
         typedef uint32_t Record __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) Record* GlobalRecord;
-        const uint8_t* records = reinterpret_cast<const uint8_t*>(fp.svtx); /* base + 32-bit byte offset, as in load_varyings */
-        const Record p0 = *(GlobalRecord)(records + (vtx[0] << 4)), p1 = *(GlobalRecord)(records + (vtx[1] << 4)),
-                     p2 = *(GlobalRecord)(records + (vtx[2] << 4));
+        const Record p0 = *(GlobalRecord)&fp.svtx[vtx[0]], p1 = *(GlobalRecord)&fp.svtx[vtx[1]], p2 = *(GlobalRecord)&fp.svtx[vtx[2]];
         c.x[0] = (int32_t)p0.x >> 8; c.y[0] = (int32_t)p0.y; c.iw[0] = __uint_as_float(p0.w);
         c.x[1] = (int32_t)p1.x >> 8; c.y[1] = (int32_t)p1.y; c.iw[1] = __uint_as_float(p1.w);
         c.x[2] = (int32_t)p2.x >> 8; c.y[2] = (int32_t)p2.y; c.iw[2] = __uint_as_float(p2.w);

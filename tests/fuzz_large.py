@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off randomised parity sweep at full target sizes (720p to 4K, up to a million triangles, up to 300 draws,
-1 or 4 samples), each frame against the oracle.  Run on a GPU: python tests/fuzz_large.py"""
+1 or 4 samples), each frame against the oracle.  Run on a GPU: python tests/fuzz_large.py [SEED...]"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ from renderer_amd.runner import SceneRunner
 from oracle import oracle
 dev = api.Device(0)
 bad = 0
-for seed in range(40):
+for seed in ([int(a) for a in sys.argv[1:]] or range(40)):
     rng = np.random.RandomState(900 + seed)
     w, h = int(rng.choice([1280, 1920, 2560, 3840])), int(rng.choice([720, 1080, 1440, 2160]))
     shader = [scenes.SHADER_PUSH_CONSTANTS, scenes.SHADER_TEST_KTX, scenes.SHADER_DUMMY][seed % 3]

@@ -678,3 +678,21 @@ def test_scheduling_settings_do_not_change_the_frame(oracle, setting, monkeypatc
             assert np.array_equal(got[img][0], oc), "image %d (frame %d): colour differs" % (img, frame)
     finally:
         dev.destroy()
+
+
+def test_vertex_records_beyond_4gb(oracle):
+    """300 draws index one vertex buffer from its start (vertexOffset 0, firstIndex advancing), so each transforms the
+    buffer up to its own largest index: 316 million transformed records, 5 GB of positions and 3.8 GB of the vertex
+    shader's other outputs.  A record's address does not fit a 32-bit byte offset from the array's base."""
+    sc = helpers.soup_scene(320, 180, 700000, 11, max_extent=0.01, depth_levels=0, z_range=(0.05, 0.95),
+                            shader=scenes.SHADER_TEST_KTX, n_draws=300,
+                            texture=dict(texels=scenes.checker_texture(64, 11), gen_mips=True, filtering=1, tiled=True, fmt=43))
+    slots = sum(int(sc.ibs[d["ib"]][d["first_index"]:d["first_index"] + d["index_count"]].max()) + 1 for d in sc.draws)
+    assert slots * 16 > (1 << 32) and slots * 12 > (3 << 30)
+    r = SceneRunner(sc)
+    try:
+        color, depth = r.render()
+    finally:
+        r.destroy()
+    oc, od, _ = oracle.render_scene(sc, threads=8)
+    assert np.array_equal(depth, od) and np.array_equal(color, oc)
