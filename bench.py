@@ -3,12 +3,15 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4] [--mode views|tiles|bands]
 
-One step = one frame: write the 320-byte uniform block (a new camera, as the reference's
-draw_frame does every frame, base_obj_viewer_app.cpp:90-141) and submit the pre-recorded
-command buffer (vk_app.cpp:463-467).  Vertex, index, texture and instance data are
-resident in HBM before the timed region starts.  The timed loop itself is compiled host code
-(renderer_amd/host/bench_loop.cpp, handed the library's entry points): no interpreter work is
-inside the clock; --python-loop drives the same calls from Python instead.
+One step = one batch of --frames-per-step frames (64), each with a camera of its own: per frame, write the
+320-byte uniform block (as the reference's draw_frame does every frame, base_obj_viewer_app.cpp:90-141) and
+submit the pre-recorded command buffer (vk_app.cpp:463-467), --frames-in-flight of them in flight (3, the
+reference's swapchain image count, vk_app.cpp:109-130, 154).  A region of a few single frames would measure how
+the pipeline fills and drains between the two device waits that bracket it: 20 frames read 47 us per frame where
+1280 read 42.9.  `ms_per_step` is per batch, `ms_per_frame` per frame; `value` counts every frame's pixels.
+Vertex, index, texture and instance data are resident in HBM before the timed region starts.  The timed loop
+itself is compiled host code (renderer_amd/host/bench_loop.cpp, handed the library's entry points): no interpreter
+work is inside the clock; --python-loop drives the same calls from Python instead.
 
 N = 1 renders BASELINE.json's configs[1]: 1920x1080, one draw of 1 002 528 triangles.
 
@@ -46,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 VALU_CYCLES = 2.4      # cycles a SIMD spends per wave-wide vector instruction when it has waves to choose from
-PRIME_STEPS = 30       # untimed frames before the caller's warm-up: the first launches of a process run at a lower clock
+PRIME_STEPS = 300      # untimed frames before the caller's warm-up: the first launches of a process run at a lower clock
 N_VIEWS = 64           # cameras of configs[4]
 
 
@@ -241,9 +244,10 @@ class NativeLoop:
 
 # ----------------------------------------------------------------------------- one measurement
 
-def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, copy_peak=False):
+def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, copy_peak=False, frames_per_step=1):
     """One workload measured as the contract says: warm-up, a barrier and a device wait on both sides of exactly
-    `steps` frames, the maximum over ranks.  Returns the result line as a dict (complete on rank 0)."""
+    `steps` steps of `frames_per_step` frames each, the maximum over ranks.  Returns the result line as a dict
+    (complete on rank 0)."""
     from renderer_amd import api, sharding
     from renderer_amd.runner import SceneRunner
     rank, world, local_rank = ctx["rank"], ctx["world"], ctx["local_rank"]
@@ -285,7 +289,7 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
         ubos = [view_ubo(scene, v) for v in mine]
         block_of = lambda i: i % len(ubos)  # noqa: E731
     else:
-        n_ubos = PRIME_STEPS + warmup + max(steps, args.profile_steps)
+        n_ubos = PRIME_STEPS + (warmup + max(steps, args.profile_steps)) * frames_per_step
         ubos = [orbit_ubo(scene, i, 0 if tiles_mode else rank) for i in range(min(n_ubos, 512))]
         block_of = lambda i: i % len(ubos)  # noqa: E731
 
@@ -382,12 +386,13 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
         run.dev.wait_idle()
         return None
 
+    fps = 1 if tiles_mode else max(1, int(frames_per_step))
     frames(0, PRIME_STEPS if not tiles_mode else min(PRIME_STEPS, 4))
-    frames(PRIME_STEPS, warmup)
+    frames(PRIME_STEPS, warmup * fps)
     sync()
     gather_s[0] = 0.0
     t0 = time.perf_counter()
-    queue_s = frames(PRIME_STEPS + warmup, steps)
+    queue_s = frames(PRIME_STEPS + warmup * fps, steps * fps)
     if dist is not None:
         torch.cuda.synchronize()
         dist.barrier()
@@ -404,7 +409,7 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
         for _ in range(args.repeats):
             sync()
             t1 = time.perf_counter()
-            frames(PRIME_STEPS + warmup, steps)
+            frames(PRIME_STEPS + warmup * fps, steps * fps)
             repeats.append((time.perf_counter() - t1) / max(steps, 1) * 1e3)
 
     gather_ms = gather_s[0] / steps * 1e3 if tiles_mode and not pipelined else None
@@ -423,7 +428,7 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
         tiles_check = "exact" if np.array_equal(frame, color) else "%d bytes differ" % int((frame != color).sum())
         if tiles_check != "exact":
             raise SystemExit("tile-sharded frame differs from the unsharded frame: " + tiles_check)
-    frames_total = steps * (1 if tiles_mode else world)
+    frames_total = steps * fps * (1 if tiles_mode else world)
     if args.one_shard_of > 1 and not tiles_mode:
         frames_total /= args.one_shard_of  # a rehearsal renders one rank's share of every frame
     pixels = scene.width * scene.height
@@ -482,12 +487,13 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
             "metric": "shaded_mpix_per_s", "value": round(mpix, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 5),
+            "frames_per_step": fps, "ms_per_frame": round(elapsed / (steps * fps) * 1e3, 5),
             "higher_is_better": True, "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None,
             "dtype": "f32+i32", "data": "synthetic",
             "mtri_per_s": round(mtri, 2),
-            "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, %d sample%s/pixel" % (
+            "config": {"workload": "%s: %dx%d, %d triangles, %d draws, test_ktx shader, %d sample%s/pixel; a step is %d frame%s, each with its own camera" % (
                 scene.name if not multiview else "config4_orbit", scene.width, scene.height, scene.triangle_count(), len(scene.draws), scene.samples,
-                "" if scene.samples == 1 else "s"),
+                "" if scene.samples == 1 else "s", fps, "" if fps == 1 else "s"),
                 "sharding": sharding_text, "frames_in_flight": run.frames_in_flight,
                 "host": "python loop over ctypes" if native is None else "compiled loop (renderer_amd/host/bench_loop.cpp), no interpreter inside the clock",
                 "seed": scene.seed},
@@ -495,6 +501,7 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
             "frame_hbm_frac": round(scene.algorithmic_bytes() * frames_total / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "host_queue_ms_per_step": None if queue_s is None else round(queue_s / steps * 1e3, 5),
             "ms_per_step_repeats": [round(x, 5) for x in repeats],
+            "ms_per_frame_repeats": [round(x / fps, 5) for x in repeats],
             "stage_ms": {k: round(v, 5) for k, v in stages.items()},
             "tiles_check": tiles_check,
             "gather_ms": None if gather_ms is None else round(gather_ms, 5),
@@ -517,8 +524,11 @@ def brief(line):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=600)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=64,
+                    help="frames in one step (one batch of synthetic input: that many camera positions of the orbit, rendered "
+                         "with --frames-in-flight of them in flight); 1 in the tile- and band-sharded modes, whose every frame ends in an exchange")
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--samples", type=int, choices=[1, 4], default=1,
                     help="samples per pixel (4: what test_app renders with, dummy_obj_viewer_app.cpp:319; resolved in linear light)")
@@ -564,7 +574,7 @@ def main():
     ctx = {"rank": rank, "world": world, "local_rank": local_rank, "dist": dist, "torch": torch, "backend": backend}
 
     out = bench_once(args, ctx, args.config, args.mode, args.steps, args.warmup,
-                     cpu=(world == 1 and not args.no_cpu), copy_peak=(world == 1))
+                     cpu=(world == 1 and not args.no_cpu), copy_peak=(world == 1), frames_per_step=args.frames_per_step)
     if world > 1 and args.mode == "views" and args.config == 1 and not args.no_extras:
         # what dist saw, and the two sharded workloads BASELINE.json names for several GPUs
         extra = copy.copy(args)

@@ -7,7 +7,7 @@ for lib in sys.argv[2:]:
     if lib != "default":
         env["RENDERER_AMD_LIB"] = os.path.abspath(lib)
     for rep in range(2):
-        out = subprocess.run([sys.executable, "bench.py", "--config", cfg, "--steps", "200", "--warmup", "20", "--no-cpu"] + os.environ.get("AB_ARGS", "").split(),
+        out = subprocess.run([sys.executable, "bench.py", "--config", cfg, "--steps", "200", "--warmup", "20", "--frames-per-step", "1", "--no-cpu"] + os.environ.get("AB_ARGS", "").split(),
                              env=env, capture_output=True, text=True, timeout=300)
         try:
             j = json.loads(out.stdout.strip().splitlines()[-1])

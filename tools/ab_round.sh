@@ -17,7 +17,7 @@ for c in $CONFIGS; do
       python - "$lib" $c $OUT/line.json <<'PY'
 import json, sys
 j = json.load(open(sys.argv[3]))
-print("%-28s cfg %s  %.5f ms  repeats %s  stages %s" % (sys.argv[1], sys.argv[2], j["ms_per_step"], j["ms_per_step_repeats"], j["stage_ms"]), flush=True)
+print("%-28s cfg %s  %.5f ms  repeats %s  stages %s" % (sys.argv[1], sys.argv[2], j["ms_per_frame"], j["ms_per_frame_repeats"], j["stage_ms"]), flush=True)
 PY
       echo "{\"lib\": \"$lib\", \"config\": $c, \"line\": $(cat $OUT/line.json)}" >> $OUT/ab.jsonl
     done

@@ -7,7 +7,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/issue_${1:-run}
 mkdir -p $OUT
-B="python3 bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu --frames-in-flight 1 --config ${2:-1}"
+B="python3 bench.py --steps 20 --warmup 5 --frames-per-step 1 --profile-steps 5 --no-cpu --frames-in-flight 1 --config ${2:-1}"
 pass() { local name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- $B > $OUT/pmc_$name.log 2>&1 || exit 1; }
 pass a SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_ANY
 pass b SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_BUSY_CYCLES TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE

@@ -9,7 +9,7 @@ for c in $CONFIGS; do
     python - $f $c $OUT/line.json <<'PY'
 import json, sys
 j = json.load(open(sys.argv[3]))
-print("in flight %s cfg %s  %.5f ms  repeats %s" % (sys.argv[1], sys.argv[2], j["ms_per_step"], j["ms_per_step_repeats"]), flush=True)
+print("in flight %s cfg %s  %.5f ms  repeats %s" % (sys.argv[1], sys.argv[2], j["ms_per_frame"], j["ms_per_frame_repeats"]), flush=True)
 PY
     echo "{\"frames_in_flight\": $f, \"config\": $c, \"line\": $(cat $OUT/line.json)}" >> $OUT/fif.jsonl
   done

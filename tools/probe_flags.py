@@ -7,7 +7,7 @@ import os, subprocess, sys, json
 cfg = sys.argv[1]
 for m in sys.argv[2:]:
     env = dict(os.environ, RND_DEBUG=m)
-    out = subprocess.run([sys.executable, "bench.py", "--config", cfg, "--steps", "200", "--warmup", "20", "--no-cpu"],
+    out = subprocess.run([sys.executable, "bench.py", "--config", cfg, "--steps", "200", "--warmup", "20", "--frames-per-step", "1", "--no-cpu"],
                          env=env, capture_output=True, text=True, timeout=300)
     try:
         j = json.loads(out.stdout.strip().splitlines()[-1])

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 for m in "$@"; do
   OUT=gpurun_out/valu_$m; mkdir -p $OUT
-  RND_DEBUG=$m timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 3 --profile-steps 3 --no-cpu --frames-in-flight 1 > $OUT/log.txt 2>&1 || exit 1
+  RND_DEBUG=$m timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 3 --frames-per-step 1 --profile-steps 3 --no-cpu --frames-in-flight 1 > $OUT/log.txt 2>&1 || exit 1
   python3 - $OUT $m <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
