@@ -8,8 +8,8 @@ neither of which needs a collective while rendering:
     (rnd_cmd_set_tile_shard); geometry is replicated, and only the finished colour image
     is exchanged -- one all_gather of equal-sized slabs, each holding the tiles one rank owns,
     which are then put back in place;
-  * sort-first bands: rank k renders a band of whole rows of tiles of ONE frame, given to the
-    library as the pass's render area and scissor.  The library then launches only the band's
+  * sort-first bands: rank k renders a band of rows of ONE frame (equal bands when the rows divide
+    evenly, whole rows of tiles otherwise), given to the library as the pass's render area and scissor.  The library then launches only the band's
     tiles and skips every draw whose box of vertices misses the band, so geometry work is
     divided as well as pixel work; the exchange is one all_gather of the bands, which are
     contiguous rows of the image.
@@ -86,8 +86,15 @@ def gather_frame(local_image, dist, world, rank=None):
 
 
 def band_rows(height, rank, world):
-    """Pixel rows [y0, y1) of rank `rank`: the rows of tiles are split as evenly as whole rows of
-    tiles allow (the first `rows % world` ranks get one more); a rank may get none (y0 == y1)."""
+    """Pixel rows [y0, y1) of rank `rank`.  When the frame's rows divide evenly among the ranks (and leave each at
+    least a row of tiles) every band is height / world rows: equal bands are what one all_gather places in the
+    frame directly, with no padding on the wire and no copy afterwards, and that is worth the row of tiles a band
+    then shares with each neighbour (both render their part of it).  Otherwise the rows of tiles are split as
+    evenly as whole rows of tiles allow (the first `rows % world` ranks get one more); a rank may then get none
+    (y0 == y1)."""
+    if height % world == 0 and height // world >= TILE:
+        rows = height // world
+        return rank * rows, (rank + 1) * rows
     tile_rows = (height + TILE - 1) // TILE
     base, extra = divmod(tile_rows, world)
     first = rank * base + min(rank, extra)

@@ -71,14 +71,18 @@ def test_pack_and_unpack_tiles(wh, world):
 @pytest.mark.parametrize("height", [32, 200, 1080, 4320, 31])
 @pytest.mark.parametrize("world", [1, 2, 3, 8, 64])
 def test_band_rows_cover_the_frame(height, world):
-    """Bands are whole rows of tiles, in rank order, disjoint, cover every row, and differ by at most one row of tiles."""
+    """Bands are in rank order, disjoint and cover every row; equal when the rows divide evenly (and leave every rank
+    a row of tiles), else whole rows of tiles that differ by at most one row of tiles."""
     spans = [sharding.band_rows(height, r, world) for r in range(world)]
     assert spans[0][0] == 0 and spans[-1][1] == height
     for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
         assert a1 == b0 and a0 <= a1
-    assert all(y0 % 32 == 0 or y0 == height for y0, _ in spans)
-    rows = [(y1 - y0 + 31) // 32 for y0, y1 in spans]
-    assert max(rows) - min(rows) <= 1
+    if height % world == 0 and height // world >= 32:
+        assert all(y1 - y0 == height // world for y0, y1 in spans)
+    else:
+        assert all(y0 % 32 == 0 or y0 == height for y0, _ in spans)
+        rows = [(y1 - y0 + 31) // 32 for y0, y1 in spans]
+        assert max(rows) - min(rows) <= 1
 
 
 def _band_worker(rank, world, height, width, port, out_dir):
@@ -112,11 +116,13 @@ def test_band_gather_over_gloo(tmp_path, world, height):
 
 def test_band_scene_cuts_area_and_scissor():
     from renderer_amd import scenes
-    sc = scenes.Scene(300, 200)
+    sc = scenes.Scene(300, 201)
     sc.scissor = (10, 50, 200, 100)
-    b = sharding.band_scene(sc, 1, 2)  # rows of tiles: 7 -> 4 + 3: band 1 = pixel rows [128, 200)
-    assert b.area == (0, 128, 300, 72) and b.scissor == (10, 128, 200, 22)
-    assert sc.area == (0, 0, 300, 200)  # the original is untouched
+    b = sharding.band_scene(sc, 1, 2)  # rows of tiles: 7 -> 4 + 3: band 1 = pixel rows [128, 201)
+    assert b.area == (0, 128, 300, 73) and b.scissor == (10, 128, 200, 22)
+    assert sc.area == (0, 0, 300, 201)  # the original is untouched
+    even = scenes.Scene(300, 200)  # 200 rows divide evenly: two bands of 100 rows, not aligned to tiles
+    assert sharding.band_scene(even, 1, 2).area == (0, 100, 300, 100)
 
 
 def test_owner_map_matches_kernel_rule():
