@@ -48,7 +48,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
-VALU_CYCLES = 2.4      # cycles a SIMD spends per wave-wide vector instruction when it has waves to choose from
+VALU_CYCLES = 4.0      # cycles of a SIMD per wave-wide vector instruction: a SIMD issues one per four-cycle turn (the tile kernel
+                       # of configs[2] takes 4.08 per vector instruction it issues); only unmixed streams of add / sub / and / or / xor /
+                       # shift-right / mov / fp32 add and mul from several waves pair up at 2.5 (tools/micro/issue_rate.hip)
+SIMDS = 1024           # 256 CUs x 4
+CLOCK_HZ = 2.4e9       # the device holds 2.39 GHz while the frames run (tools/probe_clock.sh)
+FRAME_KERNELS = ("k_draws", "k_vertex", "k_setup", "k_tile")
 PRIME_STEPS = 300      # untimed frames before the caller's warm-up: the first launches of a process run at a lower clock
 N_VIEWS = 64           # cameras of configs[4]
 
@@ -205,6 +210,17 @@ def measured_counters(kernel, config):
         if name.split("<")[0] == kernel:
             return int(row["read_bytes"] + row["write_bytes"]), row.get("valu_insts")
     return None, None
+
+
+def measured_frame_valu(config):
+    """Vector-ALU instructions of one frame's kernels together, from the same committed counter pass (None without one)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            table = json.load(f).get("config%d" % config, {})
+    except (OSError, ValueError):
+        return None
+    total = sum(row.get("valu_insts") or 0 for name, row in table.items() if name.split("<")[0] in FRAME_KERNELS)
+    return total or None
 
 
 # ----------------------------------------------------------------------------- the compiled timed loop
@@ -464,15 +480,20 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
                     "algorithmic_bytes_per_launch": share,
                     "kernel_ms": round(stages[dom], 5)}
         if valu:
-            # Vector-ALU occupation, for the record beside the HBM fraction: a SIMD with two or more waves to
-            # choose from issues one wave-wide vector instruction per VALU_CYCLES cycles (measured,
-            # tools/micro/valu_rate.hip: 2.1 for v_fma_f32, 2.4-2.6 for 32-bit integer adds; a wave on its own
-            # gets one per 4.5); 256 CUs x 4 SIMDs at 2.4 GHz
-            roofline["valu_busy"] = round(valu * VALU_CYCLES / (1024 * stages[dom] * 1e-3 * 2.4e9), 4)
+            # Vector-ALU occupation, for the record beside the HBM fraction: the kernel's vector instructions at
+            # VALU_CYCLES cycles of a SIMD each, over the SIMD cycles of its duration
+            roofline["valu_busy"] = round(valu * VALU_CYCLES / (SIMDS * stages[dom] * 1e-3 * CLOCK_HZ), 4)
+            roofline["valu_cycles_per_instruction"] = VALU_CYCLES
         if copy_peak:
             peak = measured_copy_peak(run.dev)
             roofline["peak_measured"] = round(peak, 1)  # device-to-device copy on this box, read + written bytes
             roofline["frac_of_measured"] = round(achieved / peak, 5)
+
+    # the same for the whole frame in the timed region (frames in flight overlap their kernels): what bounds the pipeline
+    frame_valu = measured_frame_valu(config) if args.samples == 1 and not tiles_mode and args.one_shard_of == 1 and not multiview else None
+    frame_valu_busy = None
+    if frame_valu:
+        frame_valu_busy = round(frame_valu * VALU_CYCLES * frames_total / world / (SIMDS * elapsed * CLOCK_HZ), 4)
 
     cpu_line = cpu_baseline(scene) if cpu and rank == 0 else None
 
@@ -499,6 +520,7 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
                 "seed": scene.seed},
             "frame_algorithmic_bytes": scene.algorithmic_bytes(),
             "frame_hbm_frac": round(scene.algorithmic_bytes() * frames_total / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
+            "frame_valu_busy": frame_valu_busy,
             "host_queue_ms_per_step": None if queue_s is None else round(queue_s / steps * 1e3, 5),
             "ms_per_step_repeats": [round(x, 5) for x in repeats],
             "ms_per_frame_repeats": [round(x / fps, 5) for x in repeats],
@@ -563,6 +585,9 @@ def main():
         import torch
         import torch.distributed as dist
         if backend == "nccl":
+            # a launcher that shows every rank one device of its own (a visible-devices mask per rank) leaves
+            # LOCAL_RANK beyond what the rank can see: its device is then the one it sees
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
