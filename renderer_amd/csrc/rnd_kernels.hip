@@ -1265,7 +1265,8 @@ template <bool PASS_TEX>
 __device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexDesc& desc, LdsLevels lds_levels, float u, float v,
                                                float dudx, float dvdx, float dudy, float dvdy, float* rgb)
 {
-    const TexView t = view_of(desc);
+    TexView t = view_of(desc);
+    if constexpr (PASS_TEX) t.table = 0u; /* the tile kernel stages the pass texture's table first */
     const float w0 = (float)t.width, h0 = (float)t.height;
     const float mxu = dudx * w0, mxv = dvdx * h0, myu = dudy * w0, myv = dvdy * h0;
     const float rx = fma32(mxv, mxv, mxu * mxu), ry = fma32(myv, myv, myu * myu);
@@ -1704,7 +1705,7 @@ __device__ __forceinline__ void raster_lists_staged(const FrameParams& fp, const
 /* sRGB tables global -> LDS, as copies that write LDS directly: a wave moves 1 KiB per instruction and holds no
  * register for it; the copies run under whatever the caller does next and are awaited (wait_for_async_copies, then
  * the workgroup's barrier) before the tables are read */
-__device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables* src)
+__device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables* src, bool swap_values = false)
 {
     static_assert(sizeof(ShadeTables) % 16 == 0, "tables are staged in 16-byte pieces");
     constexpr uint32_t PIECES = sizeof(ShadeTables) / 16;
@@ -1713,7 +1714,9 @@ __device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables*
     const uint8_t* g = reinterpret_cast<const uint8_t*>(src);
     for (uint32_t first = wave_first; first < PIECES; first += blockDim.x) { /* the same for the whole wave */
         const uint32_t i = first + (threadIdx.x & 63u);
-        if (i < PIECES) async_copy16(g + (size_t)i * 16u, lds_first + first * 16u);
+        /* swap_values: the two texel tables change places (64 pieces each, the first 128 pieces of the structure) */
+        const uint32_t from = (swap_values && i < 128u) ? (i ^ 64u) : i;
+        if (i < PIECES) async_copy16(g + (size_t)from * 16u, lds_first + first * 16u);
     }
 }
 
@@ -1821,7 +1824,11 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     const bool visible = tc.rx0 <= tc.rx1 && tc.ry0 <= tc.ry1;
     const uint32_t listed = visible ? fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE] : 0u;
     const uint32_t listed_large = visible ? fp.counters[CTR_LARGE] : 0u;
-    stage_tables(tb, fp.tables);
+    /* The texel table of the pass-wide texture is staged as value[0] whichever of the two it is: its address in LDS is
+     * then a constant of the kernel, which the table reads carry in their offset field -- a channel's lookup costs the
+     * shift that scales its byte (taken out of the texel by the instruction's operand selector) and the read. */
+    static_assert(offsetof(ShadeTables, value) == 0 && sizeof(float[2][256]) == 128 * 16, "stage_tables swaps the first 2 x 64 pieces");
+    stage_tables(tb, fp.tables, fp.pass_texture >= 0 && fp.pass_tex.srgb == 0u);
     if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
