@@ -1391,10 +1391,11 @@ __device__ __forceinline__ void corner_weights(const Corners& c, int x, int y, b
         fs = (float)(__mul24(dx2, c.y[2] - c.y[0]) - __mul24(dy2, c.x[2] - c.x[0]));
         fe[0] = (float)e0; fe[1] = (float)e1; fe[2] = (float)e2;
         if (want_derivs) {
-            /* x by +-256 changes e by -+256*dy; y by +-256 changes e by +-256*dx */
-            const int32_t gx0 = dy0 << 8, gx1 = dy1 << 8, gx2 = dy2 << 8, gy0 = dx0 << 8, gy1 = dx1 << 8, gy2 = dx2 << 8;
-            fx[0] = (float)(left ? e0 + gx0 : e0 - gx0); fx[1] = (float)(left ? e1 + gx1 : e1 - gx1); fx[2] = (float)(left ? e2 + gx2 : e2 - gx2);
-            fy[0] = (float)(up ? e0 - gy0 : e0 + gy0); fy[1] = (float)(up ? e1 - gy1 : e1 + gy1); fy[2] = (float)(up ? e2 - gy2 : e2 + gy2);
+            /* x by +-256 changes e by -+256*dy; y by +-256 changes e by +-256*dx: one 24-bit multiply-add per value
+             * (the differences are below 2^13), the direction in the factor */
+            const int32_t sl = left ? 256 : -256, su = up ? -256 : 256;
+            fx[0] = (float)(e0 + __mul24(dy0, sl)); fx[1] = (float)(e1 + __mul24(dy1, sl)); fx[2] = (float)(e2 + __mul24(dy2, sl));
+            fy[0] = (float)(e0 + __mul24(dx0, su)); fy[1] = (float)(e1 + __mul24(dx1, su)); fy[2] = (float)(e2 + __mul24(dx2, su));
         }
     } else {
         const int64_t e0 = (int64_t)dx0 * (py - c.y[1]) - (int64_t)dy0 * (px - c.x[1]);
