@@ -532,6 +532,11 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         /* the encoder looks at one threshold after the table's answer: a bucket may hold only one */
         if (k < 254 && host_tables.thr[k + 2] < next) { rnd_device_destroy(dev); return fail(RND_ERROR_INITIALIZATION_FAILED, "sRGB bucket table: two thresholds in one bucket"); }
     }
+    /* the encoder clamps a colour into the table's range [2^-13, 1) first: codes 0 and 255 must reach across its ends */
+    if (!(host_tables.thr[1] > 1.220703125e-4f && host_tables.thr[255] < 0.99999994f)) {
+        rnd_device_destroy(dev);
+        return fail(RND_ERROR_INITIALIZATION_FAILED, "sRGB bucket table: the first or last threshold lies outside the table's range");
+    }
     if (hipMalloc(reinterpret_cast<void**>(&dev->tables), sizeof(ShadeTables)) != hipSuccess) {
         rnd_device_destroy(dev);
         return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc tables failed");

@@ -68,14 +68,17 @@ __device__ __forceinline__ uint32_t depth24(float z)
 }
 
 /* linear -> sRGB code: number of thresholds <= c; the bucket table gives the number of thresholds <= the
- * bucket's lower edge, and a bucket holds at most one threshold (checked where the table is built) */
+ * bucket's lower edge, and a bucket holds at most one threshold (checked where the table is built).
+ * Without a branch: c is first brought into the table's range [2^-13, 1) -- below thr[1] (which lies above 2^-13)
+ * every value has code 0 like 2^-13 itself, from thr[255] (which lies below the largest float under 1) on every value
+ * has code 255 like that float; a NaN comes out of the median as the lower bound, code 0.  The three channels of a
+ * pixel then run their two table reads side by side instead of one branch after the other. */
 __device__ __forceinline__ uint32_t srgb_encode(const ShadeTables& tb, float c)
 {
-    if (!(c >= tb.thr[1])) return 0; /* also NaN */
-    if (c >= tb.thr[255]) return 255;
-    uint32_t key = (__float_as_uint(c) >> SRGB_LUT_SHIFT) - SRGB_LUT_FIRST; /* c in [thr[1], thr[255]) lies inside [2^-13, 1) */
+    const float cc = __builtin_amdgcn_fmed3f(c, 1.220703125e-4f, 0.99999994f);
+    const uint32_t key = (__float_as_uint(cc) >> SRGB_LUT_SHIFT) - SRGB_LUT_FIRST;
     uint32_t k = tb.lut[key];
-    k += (c >= tb.thr[k + 1]) ? 1u : 0u;
+    k += (cc >= tb.thr[k + 1]) ? 1u : 0u;
     return k;
 }
 
