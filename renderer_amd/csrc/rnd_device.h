@@ -44,6 +44,18 @@ __device__ __forceinline__ float recip32(float x)
     return 1.0f / x;
 }
 
+/* the two halves of recip32, for callers that take several reciprocals behind one test */
+__device__ __forceinline__ bool recip32_range(float x)
+{
+    const float ax = fabsf(x);
+    return ax >= 1.17549435082228750797e-38f && ax < 8.50705917302346158658e37f;
+}
+__device__ __forceinline__ float recip32_in_range(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fma32(fma32(-x, r, 1.0f), r, r);
+}
+
 /* the same for an x known to be a non-zero integer below 2^63 in magnitude (a triangle's doubled area in
  * 24.8 units): always in the range where the refined estimate is the quotient, so no test */
 __device__ __forceinline__ float recip32_of_area(float x)

@@ -1361,14 +1361,39 @@ struct EdgeFloats {
     float iw[3];
 };
 
+/* the three products of a point and their sum, in the order the reference arithmetic adds them */
+__device__ __forceinline__ float weight_products(const EdgeFloats& t, float e0, float e1, float e2, float* p)
+{
+    p[0] = (e0 * t.inv_s) * t.iw[0];
+    p[1] = (e1 * t.inv_s) * t.iw[1];
+    p[2] = (e2 * t.inv_s) * t.iw[2];
+    return (p[0] + (t.swapped ? p[2] : p[1])) + (t.swapped ? p[1] : p[2]);
+}
+
 __device__ __forceinline__ void weights_at(const EdgeFloats& t, float e0, float e1, float e2, float* q)
 {
-    const float p0 = (e0 * t.inv_s) * t.iw[0];
-    const float p1 = (e1 * t.inv_s) * t.iw[1];
-    const float p2 = (e2 * t.inv_s) * t.iw[2];
-    const float den = (p0 + (t.swapped ? p2 : p1)) + (t.swapped ? p1 : p2);
-    const float rden = recip32(den);
-    q[0] = p0 * rden; q[1] = p1 * rden; q[2] = p2 * rden;
+    const float rden = recip32(weight_products(t, e0, e1, e2, q));
+    q[0] *= rden; q[1] *= rden; q[2] *= rden;
+}
+
+/* The same at three points at once.  The refined estimate is taken for all three sums together and the division only
+ * where some lane of the wave has a sum outside the estimate's range (recip32), which is asked once for the three:
+ * one stretch of straight code instead of three branches one after the other. */
+__device__ __forceinline__ void weights_at3(const EdgeFloats& t, const float* e, const float* ex, const float* ey, float* q, float* qx, float* qy)
+{
+    const float d0 = weight_products(t, e[0], e[1], e[2], q);
+    const float d1 = weight_products(t, ex[0], ex[1], ex[2], qx);
+    const float d2 = weight_products(t, ey[0], ey[1], ey[2], qy);
+    float r0 = recip32_in_range(d0), r1 = recip32_in_range(d1), r2 = recip32_in_range(d2);
+    const bool ok0 = recip32_range(d0), ok1 = recip32_range(d1), ok2 = recip32_range(d2);
+    if (__ballot(!(ok0 && ok1 && ok2))) {
+        if (!ok0) r0 = 1.0f / d0;
+        if (!ok1) r1 = 1.0f / d1;
+        if (!ok2) r2 = 1.0f / d2;
+    }
+    q[0] *= r0; q[1] *= r0; q[2] *= r0;
+    qx[0] *= r1; qx[1] *= r1; qx[2] *= r1;
+    qy[0] *= r2; qy[1] *= r2; qy[2] *= r2;
 }
 
 /* q, qx, qy: weights at pixel (x, y), at its quad neighbour in x and at its quad neighbour in y */
@@ -1414,11 +1439,8 @@ __device__ __forceinline__ void corner_weights(const Corners& c, int x, int y, b
     t.swapped = fs < 0.0f;
     t.inv_s = recip32_of_area(fs); /* a shaded pixel has a sample inside the triangle: the area is not zero */
     t.iw[0] = c.iw[0]; t.iw[1] = c.iw[1]; t.iw[2] = c.iw[2];
-    weights_at(t, fe[0], fe[1], fe[2], q);
-    if (want_derivs) {
-        weights_at(t, fx[0], fx[1], fx[2], qnx);
-        weights_at(t, fy[0], fy[1], fy[2], qny);
-    }
+    if (want_derivs) weights_at3(t, fe, fx, fy, q, qnx, qny);
+    else weights_at(t, fe[0], fe[1], fe[2], q);
 }
 
 /* weights over a fan triangle's corners -> weights over its parent's corners */
