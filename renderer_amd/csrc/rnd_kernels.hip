@@ -1119,8 +1119,17 @@ __device__ __forceinline__ int wrap_one(int i, int n, bool tiled, bool pow2)
     return min(max(i, 0), n - 1);
 }
 
+/* What the sampler needs of one level of the pass-wide texture, kept in LDS by the tile kernel: a lane whose
+ * level differs from its neighbours' reads the level's address, its size as the floats and integers the tap
+ * arithmetic uses and the clamp bounds in two 16-byte reads, instead of shifting, clamping and converting the
+ * texture's size per lane and level. */
+struct __attribute__((aligned(16))) LevelRec {
+    unsigned long long base; /* first texel */
+    float fw, fh;            /* width and height */
+    int32_t w, wm1, hm1, wm2; /* width, width - 1, height - 1, max(width - 2, 0) */
+};
 /* pointer into LDS, typed as such so a per-lane index compiles to a ds_read and not a flat load */
-typedef const __attribute__((address_space(3))) unsigned long long* LdsLevels;
+typedef const __attribute__((address_space(3))) LevelRec* LdsLevels;
 
 /* What a sampler needs of a texture, in registers: scalar for the pass-wide texture, per lane otherwise */
 struct TexView {
@@ -1144,7 +1153,7 @@ __device__ __forceinline__ TexView view_of(const TexDesc& t)
 template <bool PASS_TEX>
 __device__ __forceinline__ const uint8_t* level_base(const TexDesc& t, LdsLevels lds_levels, uint32_t level)
 {
-    if constexpr (PASS_TEX) return reinterpret_cast<const uint8_t*>(lds_levels[level]);
+    if constexpr (PASS_TEX) return reinterpret_cast<const uint8_t*>(lds_levels[level].base);
     else return t.level[level];
 }
 
@@ -1199,21 +1208,33 @@ struct PairTaps {
     float ax, ay;
 };
 
-__device__ __forceinline__ void pair_taps(const TexView& t, uint32_t level, float u, float v, PairTaps& tp)
+__device__ __forceinline__ void pair_taps_of(float fw, float fh, int w, int wm1, int hm1, int wm2, float u, float v, PairTaps& tp)
 {
-    const int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
-    float fu = fma32(u, (float)w, -0.5f), fv = fma32(v, (float)h, -0.5f);
+    float fu = fma32(u, fw, -0.5f), fv = fma32(v, fh, -0.5f);
     fu = fminf(fmaxf(fu, -1.0e9f), 1.0e9f);
     fv = fminf(fmaxf(fv, -1.0e9f), 1.0e9f);
     const float iu = floorf(fu), iv = floorf(fv);
     tp.ax = fu - iu; tp.ay = fv - iv;
     const int i = (int)iu, j = (int)iv;
-    const int x0 = min(max(i, 0), w - 1), x1 = min(max(i + 1, 0), w - 1);
-    const int y0 = min(max(j, 0), h - 1), y1 = min(max(j + 1, 0), h - 1);
-    const int b = min(x0, max(w - 2, 0));
+    const int x0 = min(max(i, 0), wm1), x1 = min(max(i + 1, 0), wm1);
+    const int y0 = min(max(j, 0), hm1), y1 = min(max(j + 1, 0), hm1);
+    const int b = min(x0, wm2);
     tp.x0_hi = x0 != b; tp.x1_hi = x1 != b;
     tp.row[0] = (__umul24((uint32_t)y0, (uint32_t)w) + (uint32_t)b) << 2;
     tp.row[1] = (__umul24((uint32_t)y1, (uint32_t)w) + (uint32_t)b) << 2;
+}
+
+__device__ __forceinline__ void pair_taps(const TexView& t, uint32_t level, float u, float v, PairTaps& tp)
+{
+    const int w = (int)level_dim(t.width, level), h = (int)level_dim(t.height, level);
+    pair_taps_of((float)w, (float)h, w, w - 1, h - 1, max(w - 2, 0), u, v, tp);
+}
+
+/* the same with the level's figures out of the tile kernel's table */
+__device__ __forceinline__ void pair_taps(LdsLevels lds_levels, uint32_t level, float u, float v, PairTaps& tp)
+{
+    const LdsLevels r = lds_levels + level; /* member by member: a structure in LDS is not copied as a whole */
+    pair_taps_of(r->fw, r->fh, r->w, r->wm1, r->hm1, r->wm2, u, v, tp);
 }
 
 /* two neighbouring texels in one load; the address is a multiple of 4, not of 8 */
@@ -1289,7 +1310,7 @@ __device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexD
         float ax, ay;
         if (!t.tiled) {
             PairTaps tp;
-            pair_taps(t, 0, u, v, tp);
+            if constexpr (PASS_TEX) pair_taps(lds_levels, 0, u, v, tp); else pair_taps(t, 0, u, v, tp);
             const TexelPair r0 = load_texel_pair(lv, tp.row[0]), r1 = load_texel_pair(lv, tp.row[1]);
             pair_select(tp, r0, r1, p);
             ax = tp.ax; ay = tp.ay;
@@ -1316,8 +1337,8 @@ __device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexD
     float aax, aay, cax, cay;
     if (!t.tiled) {
         PairTaps ta, tc;
-        pair_taps(t, lo, u, v, ta);
-        pair_taps(t, hi, u, v, tc);
+        if constexpr (PASS_TEX) { pair_taps(lds_levels, lo, u, v, ta); pair_taps(lds_levels, hi, u, v, tc); }
+        else { pair_taps(t, lo, u, v, ta); pair_taps(t, hi, u, v, tc); }
         const TexelPair a0 = load_texel_pair(la, ta.row[0]), a1 = load_texel_pair(la, ta.row[1]);
         const TexelPair c0 = load_texel_pair(lc, tc.row[0]), c1 = load_texel_pair(lc, tc.row[1]);
         pair_select(ta, a0, a1, pa);
@@ -1819,7 +1840,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
 {
     __shared__ unsigned long long keys[TILE_PIXELS * S];
     __shared__ ShadeTables tb;
-    __shared__ unsigned long long pass_levels[16]; /* level bases of the pass-wide texture, indexable per lane */
+    __shared__ LevelRec pass_levels[16]; /* the levels of the pass-wide texture, indexable per lane */
     __shared__ uint4 stage_entry[S == 1 ? TILE_THREADS : 1], stage_corner[S == 1 ? 3 * TILE_THREADS : 1];
     __shared__ signed char wave_rows[TILE_THREADS];
     uint32_t tile, utx, uty;
@@ -1852,7 +1873,13 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
      * shift that scales its byte (taken out of the texel by the instruction's operand selector) and the read. */
     static_assert(offsetof(ShadeTables, value) == 0 && sizeof(float[2][256]) == 128 * 16, "stage_tables swaps the first 2 x 64 pieces");
     stage_tables(tb, fp.tables, fp.pass_texture >= 0 && fp.pass_tex.srgb == 0u);
-    if (threadIdx.x < 16) pass_levels[threadIdx.x] = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
+    if (threadIdx.x < 16) {
+        const int lw = (int)level_dim(fp.pass_tex.width, threadIdx.x), lh = (int)level_dim(fp.pass_tex.height, threadIdx.x);
+        LevelRec r;
+        r.base = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
+        r.fw = (float)lw; r.fh = (float)lh; r.w = lw; r.wm1 = lw - 1; r.hm1 = lh - 1; r.wm2 = max(lw - 2, 0);
+        pass_levels[threadIdx.x] = r;
+    }
     const unsigned long long clear_key = ((unsigned long long)(fp.depth_test ? fp.clear_d24 : 0xFFFFFFu) << 40) |
                                          (fp.depth_less ? 0ull : 0xFFFFFFFFFFull);
     for (uint32_t i = threadIdx.x; i < TILE_PIXELS * S; i += TILE_THREADS) keys[i] = clear_key;
