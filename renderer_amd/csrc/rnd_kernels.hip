@@ -1764,19 +1764,27 @@ __device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables*
     }
 }
 
+/* one word into an image at a 32-bit byte offset: the store takes the image's address as its scalar base and the offset
+ * as it is, where an index into a 64-bit pointer costs a 64-bit multiply-add per pixel */
+__device__ __forceinline__ void store_word(void* image, uint32_t byte_offset, uint32_t value)
+{
+    typedef __attribute__((address_space(1))) uint32_t* GlobalWord;
+    *(GlobalWord)(static_cast<uint8_t*>(image) + byte_offset) = value;
+}
+
 constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* owner word of a sample no fragment covers; otherwise slot | fan << 28 | clipped << 31 */
 
 /* Colour of pixel (x, y), whose samples are owned by vis[0..S): shade each distinct owner once,
  * resolve, encode, store. */
 template <int S>
 __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
-                                                int x, int y, size_t pi, const uint32_t* vis)
+                                                int x, int y, uint32_t pi, const uint32_t* vis)
 {
     /* no fragment landed on the pixel: the clear colour, encoded once on the host */
     bool untouched = true;
 #pragma unroll
     for (int s = 0; s < S; ++s) untouched = untouched && vis[s] == VIS_NONE;
-    if (untouched) { reinterpret_cast<uint32_t*>(fp.color)[pi] = fp.clear_packed; return; }
+    if (untouched) { store_word(fp.color, pi << 2, fp.clear_packed); return; }
     float smp[S][4];
     if constexpr (S == 1) {
         if (RND_PROBE(fp, 1u)) {
@@ -1823,7 +1831,7 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = ((smp[0][c] + smp[1][c]) + (smp[2][c] + smp[3][c])) * 0.25f;
     }
-    reinterpret_cast<uint32_t*>(fp.color)[pi] = pack_color(fp, tb, acc);
+    store_word(fp.color, pi << 2, pack_color(fp, tb, acc));
 }
 
 /* One workgroup per 32x32 tile, in two phases.  Rasterise the tile's triangles into one 64-bit
@@ -1922,12 +1930,12 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
         const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
         if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
-        const size_t pi = (size_t)y * fp.width + (size_t)x;
+        const uint32_t pi = (uint32_t)y * fp.width + (uint32_t)x; /* a target is at most 8192 x 8192 pixels of 4 samples: byte offsets fit 32 bits */
         uint32_t vis[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const unsigned long long k = keys[p * S + s];
-            fp.depth[pi * S + s] = fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24;
+            store_word(fp.depth, (pi * S + s) << 2, fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24);
             vis[s] = VIS_NONE;
             if (k != clear_key) {
                 const uint32_t low = (uint32_t)(k >> 8);
