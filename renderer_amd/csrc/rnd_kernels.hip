@@ -730,6 +730,14 @@ struct EdgeSetup {
         atomicMin(&tc.keys[word_index], ((unsigned long long)hi << 32) | pay_lo);
     }
 
+    /* the same with the word's byte offset in the tile's array, which the walks step instead of an index */
+    __device__ __forceinline__ void emit_at(const TileCtx& tc, uint32_t byte_offset, I e1, I e2) const
+    {
+        const float z = fma32((float)e2, gz2, fma32((float)e1, gz1, z0));
+        const uint32_t hi = (depth24(z) << 8) | pay_hi;
+        atomicMin(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(tc.keys) + byte_offset), ((unsigned long long)hi << 32) | pay_lo);
+    }
+
     __device__ __forceinline__ void pixel(const TileCtx& tc, int x, int y) const
     {
         const uint32_t pix = (uint32_t)((y - tc.py0) * TILE_W + (x - tc.px0));
@@ -811,18 +819,19 @@ struct WalkSetup {
         int32_t a2 = e2 + __mul24(col, sx2) + __mul24(row, sy2);
         /* from the last column of a strip to the first of the next: two down, ow - 1 back */
         const int32_t nl0 = WALK_ROWS * sy0 - __mul24(ow - 1, sx0), nl1 = WALK_ROWS * sy1 - __mul24(ow - 1, sx1), nl2 = WALK_ROWS * sy2 - __mul24(ow - 1, sx2);
-        uint32_t pix = (((box >> 5) & 31u) + (uint32_t)row) * TILE_W + (box & 31u) + (uint32_t)col;
+        uint32_t pix8 = ((((box >> 5) & 31u) + (uint32_t)row) * TILE_W + (box & 31u) + (uint32_t)col) * 8u; /* byte offset of the pixel's word */
         /* a box of odd height has no second row in its last strip, whose steps are those from `single` on */
         const int single = (oh & 1) ? __mul24(ow, oh >> 1) : 0x7fffffff;
         EdgeSetup<int32_t, 1> es; /* only its depth plane is used */
         es.z0 = z0; es.gz1 = gz1; es.gz2 = gz2; es.pay_lo = pay_lo; es.pay_hi = pay_hi;
+        const uint32_t next_strip8 = (uint32_t)(WALK_ROWS * TILE_W - ow + 1) * 8u;
         for (int i = k0; i < k1; ++i) {
-            if ((a0 | a1 | a2) >= 0) es.emit(tc, pix, a1 + b1, a2 + b2);
+            if ((a0 | a1 | a2) >= 0) es.emit_at(tc, pix8, a1 + b1, a2 + b2);
             const int32_t c0 = a0 + sy0, c1 = a1 + sy1, c2 = a2 + sy2;
-            if ((c0 | c1 | c2) >= 0 && i < single) es.emit(tc, pix + TILE_W, c1 + b1, c2 + b2);
+            if ((c0 | c1 | c2) >= 0 && i < single) es.emit_at(tc, pix8 + TILE_W * 8u, c1 + b1, c2 + b2);
             const bool last = ++col == ow;
             a0 += last ? nl0 : sx0; a1 += last ? nl1 : sx1; a2 += last ? nl2 : sx2;
-            pix += last ? (uint32_t)(WALK_ROWS * TILE_W - ow + 1) : 1u;
+            pix8 += last ? next_strip8 : 8u;
             if (last) col = 0;
         }
     }
@@ -907,15 +916,16 @@ __device__ __forceinline__ void raster_lane(const FrameParams& fp, const TileCtx
         const int h = y1 - y0 + 1;
         const int steps = walk_steps(w, h);
         const int single = (h & 1) ? steps - w : 0x7fffffff; /* the steps of an odd box's last strip have one row */
-        uint32_t pix = (uint32_t)((y0 - tc.py0) * TILE_W + (x0 - tc.px0));
+        uint32_t pix8 = (uint32_t)((y0 - tc.py0) * TILE_W + (x0 - tc.px0)) * 8u; /* byte offset of the pixel's word */
+        const uint32_t next_strip8 = (uint32_t)(WALK_ROWS * TILE_W - w + 1) * 8u;
         int col = 0;
         for (int i = 0; i < steps; ++i) {
-            if ((e0 | e1 | e2) >= 0) es.emit(tc, pix, e1 + es.bias1, e2 + es.bias2);
+            if ((e0 | e1 | e2) >= 0) es.emit_at(tc, pix8, e1 + es.bias1, e2 + es.bias2);
             const int32_t c0 = e0 + sy0, c1 = e1 + sy1, c2 = e2 + sy2;
-            if ((c0 | c1 | c2) >= 0 && i < single) es.emit(tc, pix + TILE_W, c1 + es.bias1, c2 + es.bias2);
+            if ((c0 | c1 | c2) >= 0 && i < single) es.emit_at(tc, pix8 + TILE_W * 8u, c1 + es.bias1, c2 + es.bias2);
             const bool last = ++col == w;
             e0 += last ? nl0 : sx0; e1 += last ? nl1 : sx1; e2 += last ? nl2 : sx2;
-            pix += last ? (uint32_t)(WALK_ROWS * TILE_W - w + 1) : 1u;
+            pix8 += last ? next_strip8 : 8u;
             if (last) col = 0;
         }
     } else {
