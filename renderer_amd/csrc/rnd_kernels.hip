@@ -61,6 +61,10 @@ __device__ __forceinline__ uint32_t pack_bbox(int tx0, int ty0, int tx1, int ty1
     return (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
 }
 
+/* row of tiles of pixel row y, which pixel_box has clamped to the target (never negative): an unsigned division, one
+ * shift for the usual tile height, where the signed one rounds toward zero in three instructions */
+__device__ __forceinline__ int tile_row(int y) { return (int)((uint32_t)y / (uint32_t)TILE_H); }
+
 /* primitive slot -> draw, triangle */
 __device__ __forceinline__ void slot_to_prim(const FrameParams& fp, uint32_t slot, uint32_t& draw, uint32_t& tri)
 {
@@ -521,16 +525,23 @@ __device__ __forceinline__ void bin_wave(const FrameParams& fp, bool valid, cons
     }
     /* issue every atomic before using any result */
     uint32_t base0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    const int t1 = tile_of_first(1), t2 = tile_of_first(2), t3 = tile_of_first(3);
+    /* a wave of a fine mesh often has no box of more than one tile: the second to fourth tiles are not even worked out then */
+    int t1 = -1, t2 = -1, t3 = -1;
+    const bool several = __ballot(n > 1) != 0ull;
+    if (several) { t1 = tile_of_first(1); t2 = tile_of_first(2); t3 = tile_of_first(3); }
     if ((int)lane == leader) base0 = atomicAdd(&fp.tile_count[(size_t)t0 * TILE_COUNT_STRIDE], group);
-    if (t1 >= 0) p1 = atomicAdd(&fp.tile_count[(size_t)t1 * TILE_COUNT_STRIDE], 1u);
-    if (t2 >= 0) p2 = atomicAdd(&fp.tile_count[(size_t)t2 * TILE_COUNT_STRIDE], 1u);
-    if (t3 >= 0) p3 = atomicAdd(&fp.tile_count[(size_t)t3 * TILE_COUNT_STRIDE], 1u);
+    if (several) {
+        if (t1 >= 0) p1 = atomicAdd(&fp.tile_count[(size_t)t1 * TILE_COUNT_STRIDE], 1u);
+        if (t2 >= 0) p2 = atomicAdd(&fp.tile_count[(size_t)t2 * TILE_COUNT_STRIDE], 1u);
+        if (t3 >= 0) p3 = atomicAdd(&fp.tile_count[(size_t)t3 * TILE_COUNT_STRIDE], 1u);
+    }
     base0 = (uint32_t)__shfl((int)base0, leader < 0 ? (int)lane : leader);
     if (t0 >= 0) put_entry(fp, t0, base0 + rank, e);
-    if (t1 >= 0) put_entry(fp, t1, p1, e);
-    if (t2 >= 0) put_entry(fp, t2, p2, e);
-    if (t3 >= 0) put_entry(fp, t3, p3, e);
+    if (several) {
+        if (t1 >= 0) put_entry(fp, t1, p1, e);
+        if (t2 >= 0) put_entry(fp, t2, p2, e);
+        if (t3 >= 0) put_entry(fp, t3, p3, e);
+    }
     for (int k = 4; k < n; ++k) {
         const int t = tile_of(k);
         if (t >= 0) put_entry(fp, t, atomicAdd(&fp.tile_count[(size_t)t * TILE_COUNT_STRIDE], 1u), e);
@@ -589,7 +600,7 @@ __device__ __forceinline__ void clip_primitive(const FrameParams& fp, const Draw
         fp.clip_tris[idx] = ct;
         if (vis) {
             TileEntry e = {idx, 0u, 0u, slot | ((uint32_t)(k - 1) << ENTRY_SUB_SHIFT) | FLAG_CLIPPED};
-            bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, y0 / TILE_H, x1 >> TILE_SHIFT, y1 / TILE_H));
+            bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, tile_row(y0), x1 >> TILE_SHIFT, tile_row(y1)));
         }
     }
 }
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
             int x0, y0, x1, y1;
             if (setup_tri(t, d.cull_mode, d.front_face) && pixel_box(fp, t, x0, y0, x1, y1)) {
                 valid = true;
-                box = pack_bbox(x0 >> TILE_SHIFT, y0 / TILE_H, x1 >> TILE_SHIFT, y1 / TILE_H);
+                box = pack_bbox(x0 >> TILE_SHIFT, tile_row(y0), x1 >> TILE_SHIFT, tile_row(y1));
                 const uint32_t v0 = svtx_base + pf.idx[0], v1 = svtx_base + pf.idx[1], v2 = svtx_base + pf.idx[2];
                 /* what shading needs, in the primitive's own corner order */
                 PrimRec pr = {v0, v1, v2, c.draw};
