@@ -212,15 +212,18 @@ def measured_counters(kernel, config):
     return None, None
 
 
-def measured_frame_valu(config):
-    """Vector-ALU instructions of one frame's kernels together, from the same committed counter pass (None without one)."""
+def measured_frame_totals(config):
+    """Vector-ALU instructions and L2<->HBM bytes of one frame's kernels together, from the same committed counter pass
+    ((None, None) without one)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             table = json.load(f).get("config%d" % config, {})
     except (OSError, ValueError):
-        return None
-    total = sum(row.get("valu_insts") or 0 for name, row in table.items() if name.split("<")[0] in FRAME_KERNELS)
-    return total or None
+        return None, None
+    rows = [row for name, row in table.items() if name.split("<")[0] in FRAME_KERNELS]
+    valu = sum(row.get("valu_insts") or 0 for row in rows)
+    traffic = sum((row.get("read_bytes") or 0) + (row.get("write_bytes") or 0) for row in rows)
+    return (valu or None), (int(traffic) or None)
 
 
 # ----------------------------------------------------------------------------- the compiled timed loop
@@ -490,10 +493,14 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
             roofline["frac_of_measured"] = round(achieved / peak, 5)
 
     # the same for the whole frame in the timed region (frames in flight overlap their kernels): what bounds the pipeline
-    frame_valu = measured_frame_valu(config) if args.samples == 1 and not tiles_mode and args.one_shard_of == 1 and not multiview else None
-    frame_valu_busy = None
+    whole_frames = args.samples == 1 and not tiles_mode and args.one_shard_of == 1 and (not multiview or world == 1)
+    frame_valu, frame_traffic = measured_frame_totals(config) if whole_frames else (None, None)
+    frame_valu_busy = frame_traffic_frac = None
     if frame_valu:
         frame_valu_busy = round(frame_valu * VALU_CYCLES * frames_total / world / (SIMDS * elapsed * CLOCK_HZ), 4)
+    if frame_traffic:
+        # what the frames really moved between L2 and HBM (intermediates and re-read lines included), against the same peak
+        frame_traffic_frac = round(frame_traffic * frames_total / world / elapsed / 1e9 / HBM_PEAK_GBS, 4)
 
     cpu_line = cpu_baseline(scene) if cpu and rank == 0 else None
 
@@ -521,6 +528,7 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
             "frame_algorithmic_bytes": scene.algorithmic_bytes(),
             "frame_hbm_frac": round(scene.algorithmic_bytes() * frames_total / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "frame_valu_busy": frame_valu_busy,
+            "frame_traffic_bytes": frame_traffic, "frame_traffic_hbm_frac": frame_traffic_frac,
             "host_queue_ms_per_step": None if queue_s is None else round(queue_s / steps * 1e3, 5),
             "ms_per_step_repeats": [round(x, 5) for x in repeats],
             "ms_per_frame_repeats": [round(x / fps, 5) for x in repeats],

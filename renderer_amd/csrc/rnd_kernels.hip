@@ -1448,7 +1448,7 @@ __device__ __forceinline__ void corner_weights(const Corners& c, int x, int y, b
     const bool left = (x & 1) != 0, up = (y & 1) != 0; /* the neighbour is at x-1 / y-1 */
     const int ext = max(max(c.x[0], max(c.x[1], c.x[2])) - min(c.x[0], min(c.x[1], c.x[2])),
                         max(c.y[0], max(c.y[1], c.y[2])) - min(c.y[0], min(c.y[1], c.y[2])));
-    float fe[3], fx[3] = {0.f, 0.f, 0.f}, fy[3] = {0.f, 0.f, 0.f}, fs;
+    float fe[3], fx[3], fy[3], fs; /* fx, fy: only where derivatives are wanted, and only read there */
     /* a shaded pixel has a sample inside the triangle, so it and its quad neighbours are within two
      * pixels of the box: with a box under 2^13 every factor below stays under 2^14 */
     if (ext < (1 << 13)) {
@@ -1504,7 +1504,7 @@ __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Shad
     const bool want_derivs = texture >= 0;
     /* weights over the parent's corners at the pixel centre, and at the neighbour in x and the
      * neighbour in y of the 2x2 quad (same primitive, extrapolated) for the derivatives */
-    float lam[3], lnx[3] = {0.f, 0.f, 0.f}, lny[3] = {0.f, 0.f, 0.f};
+    float lam[3], lnx[3], lny[3]; /* lnx, lny: written and read only where derivatives are wanted */
     corner_weights(c, x, y, want_derivs, lam, lnx, lny);
     if (bary) {
         to_parent(bary, lam);
