@@ -113,6 +113,9 @@ const char* rnd_last_error(void);
 /* vk_utils::context::init (context.cpp:238-258): one device object per GPU.
  * stream: a hipStream_t to launch on, or NULL for a stream owned by the device. */
 int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out);
+/* The device goes last, as the reference destroys its context last (context.cpp:567-574): every buffer, texture, target,
+ * pipeline, command buffer and fence points back at its device, and destroying it while any of them is alive fails with
+ * RND_ERROR_INVALID_ARGUMENT and leaves the device as it is. */
 int rnd_device_destroy(rnd_device dev);
 int rnd_device_wait_idle(rnd_device dev);                 /* vkDeviceWaitIdle (vk_app.cpp:412-418) */
 void* rnd_device_stream(rnd_device dev);                  /* the hipStream_t uploads and copies are queued on */

@@ -6,6 +6,7 @@ Errors follow the reference's default build: a non-zero return becomes an
 exception carrying the code and message (error_handler.hpp:9-48).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -58,6 +59,12 @@ class _Handle:
     def __init__(self):
         self.h = C.c_void_p()
 
+    def _child_of(self, dev):
+        """Every object created on a device points back at it in the library and is destroyed before it
+        (Device.destroy sees to that for the objects still alive)."""
+        self.dev = dev
+        dev._children.add(self)
+
     def destroy(self):
         if self.h:
             getattr(_lib.load(), self._destroy_name)(self.h)
@@ -76,7 +83,17 @@ class Device(_Handle):
 
     def __init__(self, ordinal=0, stream=None):
         super().__init__()
+        self._children = weakref.WeakSet()
         _check(_lib.load().rnd_device_create(ordinal, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+
+    def destroy(self):
+        """Destroys what was created on the device and is still alive, then the device: the library refuses to destroy a
+        device that objects still point at (the reference destroys its context last, context.cpp:567-574)."""
+        if self.h:
+            for child in list(self._children):
+                child.destroy()
+            _check(_lib.load().rnd_device_destroy(self.h))
+            self.h = C.c_void_p()
 
     def wait_idle(self):
         _check(_lib.load().rnd_device_wait_idle(self.h))
@@ -102,7 +119,7 @@ class Buffer(_Handle):
 
     def __init__(self, dev, usage, data=None, nbytes=None):
         super().__init__()
-        self.dev = dev
+        self._child_of(dev)
         if data is not None:
             a, p, n = _as_bytes(data)
             self.nbytes = n
@@ -131,7 +148,7 @@ class Texture(_Handle):
     def __init__(self, dev, texels, fmt=FORMAT_R8G8B8A8_SRGB, gen_mips=True, filtering=FILTER_LINEAR, tiled=False,
                  levels=None):
         super().__init__()
-        self.dev = dev
+        self._child_of(dev)
         si = SamplerInfo(filtering, 1 if tiled else 0, 0.0)
         if levels is None:
             a = np.ascontiguousarray(texels, dtype=np.uint8)
@@ -163,7 +180,8 @@ class Target(_Handle):
 
     def __init__(self, dev, width, height, color_format=FORMAT_R8G8B8A8_SRGB, samples=1):
         super().__init__()
-        self.dev, self.width, self.height, self.samples, self.color_format = dev, width, height, samples, color_format
+        self._child_of(dev)
+        self.width, self.height, self.samples, self.color_format = width, height, samples, color_format
         _check(_lib.load().rnd_target_create(dev.h, width, height, color_format, FORMAT_D24_UNORM_S8_UINT, samples,
                                             C.byref(self.h)))
 
@@ -194,7 +212,7 @@ class Pipeline(_Handle):
                  depth_compare=COMPARE_LESS_OR_EQUAL, samples=1, topology=TOPOLOGY_TRIANGLE_LIST,
                  color_write_mask=0xF, blend_enable=False):
         super().__init__()
-        self.dev = dev  # children keep their device alive: it must be destroyed last
+        self._child_of(dev)
         self.info = PipelineInfo(
             shader,
             VertexAttribute(FORMAT_R32G32B32_SFLOAT, off_pos),
@@ -210,7 +228,7 @@ class Fence(_Handle):
 
     def __init__(self, dev):
         super().__init__()
-        self.dev = dev  # rnd_fence_destroy reads the device
+        self._child_of(dev)
         _check(_lib.load().rnd_fence_create(dev.h, C.byref(self.h)))
 
     def wait(self):
@@ -223,7 +241,7 @@ class CommandBuffer(_Handle):
 
     def __init__(self, dev):
         super().__init__()
-        self.dev = dev
+        self._child_of(dev)
         self._keep = []
         _check(_lib.load().rnd_cmd_create(dev.h, C.byref(self.h)))
 

@@ -100,6 +100,8 @@ struct rnd_device_t {
     std::vector<rnd_target> targets;
     hipEvent_t order_ev = nullptr;
     uint64_t upload_seq = 0;       /* counts the pieces of work queued on the device's own stream */
+    int live_objects = 0;          /* buffers, textures, targets, pipelines, command buffers and fences not yet destroyed: each holds a
+                                    * pointer to this object, so the device outlives them (rnd_device_destroy refuses while any is left) */
     uint64_t index_epoch = 0;      /* counts writes into index buffers: vertex counts scanned before the last one are stale */
     bool profiling = false;
     hipEvent_t ev[RND_STAGE_COUNT + 1] = {};
@@ -483,6 +485,7 @@ int texture_alloc(rnd_device dev, uint32_t w, uint32_t h, int32_t format, uint32
         }
     }
     *out = t;
+    ++dev->live_objects;
     return RND_SUCCESS;
 }
 
@@ -585,6 +588,11 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
 int rnd_device_destroy(rnd_device dev)
 {
     if (!dev) return RND_SUCCESS;
+    /* every object created on the device points back at it and its destroy call follows that pointer: the device goes last,
+     * as the reference destroys its context last (context.cpp:567-574) */
+    if (dev->live_objects > 0)
+        return fail(RND_ERROR_INVALID_ARGUMENT, "device_destroy: " + std::to_string(dev->live_objects) +
+                    " object(s) created on this device are still alive; destroy them first (the device is left as it is)");
     (void)hipSetDevice(dev->ordinal);
     (void)sync_all(dev);
     if (dev->order_ev) (void)hipEventDestroy(dev->order_ev);
@@ -639,6 +647,7 @@ int rnd_buffer_create(rnd_device dev, uint64_t bytes, uint32_t usage, const void
         if (e != hipSuccess) { (void)hipFree(p); return fail(RND_ERROR_DEVICE_LOST, "buffer upload failed"); }
     }
     rnd_buffer b = new rnd_buffer_t{dev, p, bytes, usage};
+    ++dev->live_objects;
     *out = b;
     return RND_SUCCESS;
 }
@@ -706,6 +715,7 @@ int rnd_buffer_destroy(rnd_buffer buf)
     if (buf->dev->pending.dst >= buf->ptr && buf->dev->pending.dst < buf->ptr + buf->bytes) buf->dev->pending.dst = nullptr;
     (void)sync_all(buf->dev);
     (void)hipFree(buf->ptr);
+    --buf->dev->live_objects;
     delete buf;
     return RND_SUCCESS;
 }
@@ -787,6 +797,7 @@ int rnd_texture_destroy(rnd_texture tex)
     (void)hipSetDevice(tex->dev->ordinal);
     (void)sync_all(tex->dev);
     for (uint32_t l = 0; l < 16; ++l) if (tex->level_ptr[l]) (void)hipFree(tex->level_ptr[l]);
+    --tex->dev->live_objects;
     delete tex;
     return RND_SUCCESS;
 }
@@ -807,6 +818,7 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
     if (int r = set_device(dev)) return r;
     rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, nullptr, nullptr, false};
     if (hipEventCreateWithFlags(&t->order_ev, hipEventDisableTiming) != hipSuccess) { delete t; return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed"); }
+    ++dev->live_objects; /* from here on rnd_target_destroy releases it, on the failure paths below too */
     size_t px = (size_t)width * height;
     hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&t->color), px * 4);
     hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&t->depth), px * samples * 4);
@@ -867,6 +879,7 @@ int rnd_target_destroy(rnd_target target)
     { auto& list = target->dev->targets; list.erase(std::remove(list.begin(), list.end(), target), list.end()); }
     if (target->color) (void)hipFree(target->color);
     if (target->depth) (void)hipFree(target->depth);
+    --target->dev->live_objects;
     delete target;
     return RND_SUCCESS;
 }
@@ -896,11 +909,14 @@ int rnd_pipeline_create(rnd_device dev, const rnd_pipeline_info* info, rnd_pipel
     if (info->color_write_mask != 0xFu) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "colour write mask must be RGBA");
     if (info->blend_enable) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "blending is not supported");
     *out = new rnd_pipeline_t{dev, *info};
+    ++dev->live_objects;
     return RND_SUCCESS;
 }
 
 int rnd_pipeline_destroy(rnd_pipeline p)
 {
+    if (!p) return RND_SUCCESS;
+    --p->dev->live_objects;
     delete p;
     return RND_SUCCESS;
 }
@@ -926,6 +942,7 @@ int rnd_cmd_create(rnd_device dev, rnd_cmd* out)
         return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed");
     }
     dev->cmds.push_back(c);
+    ++dev->live_objects;
     *out = c;
     return RND_SUCCESS;
 }
@@ -1348,6 +1365,7 @@ int rnd_cmd_destroy(rnd_cmd cmd)
     list.erase(std::remove(list.begin(), list.end(), cmd), list.end());
     if (cmd->done_ev) (void)hipEventDestroy(cmd->done_ev);
     if (cmd->own_stream) (void)hipStreamDestroy(cmd->stream);
+    --cmd->dev->live_objects;
     delete cmd;
     return RND_SUCCESS;
 }
@@ -1520,6 +1538,7 @@ int rnd_fence_create(rnd_device dev, rnd_fence* out)
     rnd_fence f = new rnd_fence_t{dev, nullptr, false};
     hipError_t e = hipEventCreateWithFlags(&f->ev, hipEventDisableTiming);
     if (e != hipSuccess) { delete f; return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed"); }
+    ++dev->live_objects;
     *out = f;
     return RND_SUCCESS;
 }
@@ -1539,6 +1558,7 @@ int rnd_fence_destroy(rnd_fence fence)
     if (!fence) return RND_SUCCESS;
     (void)hipSetDevice(fence->dev->ordinal);
     (void)hipEventDestroy(fence->ev);
+    --fence->dev->live_objects;
     delete fence;
     return RND_SUCCESS;
 }

@@ -696,3 +696,24 @@ def test_vertex_records_beyond_4gb(oracle):
         r.destroy()
     oc, od, _ = oracle.render_scene(sc, threads=8)
     assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
+def test_a_device_outlives_what_was_created_on_it():
+    """Every object points back at its device and its destroy call follows that pointer (the reference destroys its
+    context last, context.cpp:567-574): the library refuses to destroy a device that objects still point at, and the
+    Python wrapper destroys the live ones first."""
+    from renderer_amd import _lib
+    lib = _lib.load()
+    dev = api.Device(0)
+    buf = api.Buffer(dev, api.BUFFER_USAGE_VERTEX, nbytes=64)
+    fence = api.Fence(dev)
+    assert lib.rnd_device_destroy(dev.h) != 0
+    assert "still alive" in lib.rnd_last_error().decode()
+    buf.write(np.arange(16, dtype=np.float32))  # the device is as it was
+    assert np.array_equal(buf.read().view(np.float32), np.arange(16, dtype=np.float32))
+    buf.destroy()
+    assert lib.rnd_device_destroy(dev.h) != 0  # the fence is left
+    dev.destroy()  # destroys the fence, then the device
+    assert not fence.h and not dev.h
+    fence.destroy()  # a second destroy of either is a no-op
+    dev.destroy()
