@@ -109,7 +109,7 @@ struct SVtx {
  * dot per fragment, up to float rounding -- and the record holds one float where the normal would take three. */
 struct SVary {
     float light;      /* zero for the dummy shader, which does not light */
-    float u, v;       /* a_uv as stored */
+    float u, v;       /* v_uv: a_uv, with v flipped for the dummy shader (dummy.vert.glsl:25) */
 };
 static_assert(sizeof(SVary) == 12, "packed");
 

@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     fp.svtx[d.svtx_base + v] = out;
     /* the rest of the vertex shader: v_normal (test_ktx.vert:30, push_constants.vert:30) and v_uv */
     SVary vo;
-    vo.light = 0.0f; vo.u = uv[0]; vo.v = uv[1];
+    vo.light = 0.0f; vo.u = uv[0];
+    vo.v = d.shader == 0 ? 1.0f - uv[1] : uv[1]; /* dummy.vert.glsl:25 flips v */
     if (d.shader != 0) {
         const float len2 = fma32(nrm[2], nrm[2], fma32(nrm[1], nrm[1], nrm[0] * nrm[0]));
         const float len = sqrtf(len2);
@@ -1090,7 +1091,7 @@ __device__ __forceinline__ void raster_batch(const FrameParams& fp, const TileCt
 struct Varyings { float light; float uv[2]; };
 
 /* Vertex-shader outputs other than the position, as the vertex kernel left them */
-__device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vtx, int shader, Varyings& out)
+__device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vtx, Varyings& out)
 {
     /* three adjacent words: one 12-byte load.  The address is 64 bits per lane: draws that index one vertex buffer
      * from its start each transform it up to their largest index, and a pass of some hundred such draws holds more
@@ -1100,7 +1101,7 @@ __device__ __forceinline__ void load_varyings(const FrameParams& fp, uint32_t vt
     const Triple a = *(GlobalTriple)&fp.svary[vtx];
     out.light = a.x;
     out.uv[0] = a.y;
-    out.uv[1] = shader == 0 ? 1.0f - a.z : a.z; /* dummy.vert.glsl:25 flips v */
+    out.uv[1] = a.z; /* the vertex kernel has applied the dummy shader's flip of v */
 }
 
 __device__ __forceinline__ float interp(const float* lam, float a0, float a1, float a2)
@@ -1574,9 +1575,9 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
     int shader, texture;
     shader_and_texture(fp, draw, shader, texture);
     Varyings v0, v1, v2;
-    load_varyings(fp, vtx[0], shader, v0);
-    load_varyings(fp, vtx[1], shader, v1);
-    load_varyings(fp, vtx[2], shader, v2);
+    load_varyings(fp, vtx[0], v0);
+    load_varyings(fp, vtx[1], v1);
+    load_varyings(fp, vtx[2], v2);
     Corners c;
     const float* bary = nullptr;
     if (!clipped) {
