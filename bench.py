@@ -40,6 +40,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -56,6 +57,7 @@ CLOCK_HZ = 2.4e9       # the device holds 2.39 GHz while the frames run (tools/p
 FRAME_KERNELS = ("k_draws", "k_vertex", "k_setup", "k_tile")
 PRIME_STEPS = 300      # untimed frames before the caller's warm-up: the first launches of a process run at a lower clock
 N_VIEWS = 64           # cameras of configs[4]
+LEGS_TIME_LIMIT_S = 420 # N > 1: the two sharded legs together; beyond it the line is printed without the leg that hangs
 
 
 # ----------------------------------------------------------------------------- launching N ranks
@@ -615,7 +617,24 @@ def main():
         # a leg that fails says so in its place: the line's own measurement above is already taken
         legs = (("bands_8k", lambda: bench_once(extra, ctx, 3, "bands", max(10, min(args.steps, 40)), max(2, min(args.warmup, 5)), profile=False)),
                 ("multiview_10m", lambda: bench_once(extra, ctx, 4, "views", 3 * max(1, N_VIEWS // world), max(1, N_VIEWS // world), profile=False)))
+        # The line's own measurement is taken.  A leg in which one rank fails and the others wait for it in a collective would
+        # keep every rank waiting until the process group's own time limit ends them all without a line: every rank therefore
+        # carries a timer over the legs (they take well under a minute together), and when it fires rank 0 prints the line
+        # with the leg marked as timed out and every rank ends with status 0.
+        state = {"leg": legs[0][0]}
+
+        def give_up():
+            if rank == 0:
+                out[state["leg"]] = {"error": "timed out after %d s (some rank did not reach a collective)" % LEGS_TIME_LIMIT_S}
+                out["n_gpus"] = world
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(LEGS_TIME_LIMIT_S, give_up)
+        timer.daemon = True
+        timer.start()
         for name, leg in legs:
+            state["leg"] = name
             try:
                 line = leg()
                 if rank == 0:
@@ -623,6 +642,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - reported, not hidden
                 if rank == 0:
                     out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        timer.cancel()
     if rank == 0:
         out["n_gpus"] = dist.get_world_size() if dist is not None else 1
         print(json.dumps(out), flush=True)
