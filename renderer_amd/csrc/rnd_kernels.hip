@@ -728,8 +728,12 @@ struct EdgeSetup {
         const float inv_area = recip32_of_area((float)area2); /* setup lists no triangle of zero area */
         z0 = t.z[0]; gz1 = (t.z[1] - t.z[0]) * inv_area; gz2 = (t.z[2] - t.z[0]) * inv_area;
         if (!fp.depth_test) z0 = gz1 = gz2 = 0.0f; /* no depth test: every fragment's depth is 0 and the order decides */
+        /* Equal depths: under LESS the first fragment submitted stays, otherwise (LESS_OR_EQUAL, no depth test) the last one
+         * wins, and the minimum over the words must say the same -- between primitives (their slots) and between the fan
+         * triangles of one clipped primitive, which overlap where snapping has folded a sliver: the fan index counts the
+         * same way as the slot (complemented when the last is to win) */
         const uint32_t ord = fp.depth_less ? t.slot : ~t.slot;
-        pay_lo = (ord << 8) | t.payload_lo;
+        pay_lo = (ord << 8) | (fp.depth_less ? t.payload_lo : (t.payload_lo ^ 7u));
         pay_hi = ord >> 24;
     }
 
@@ -1961,7 +1965,8 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
             vis[s] = VIS_NONE;
             if (k != clear_key) {
                 const uint32_t low = (uint32_t)(k >> 8);
-                vis[s] = ((fp.depth_less ? low : ~low) & SLOT_MASK) | ((uint32_t)(k & 15ull) << ENTRY_SUB_SHIFT);
+                const uint32_t fan_clipped = (uint32_t)(k & 15ull) ^ (fp.depth_less ? 0u : 7u); /* the fan index as the rasteriser complemented it */
+                vis[s] = ((fp.depth_less ? low : ~low) & SLOT_MASK) | (fan_clipped << ENTRY_SUB_SHIFT);
             }
         }
         shade_and_store<S>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);

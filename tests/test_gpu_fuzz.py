@@ -37,3 +37,10 @@ def test_soup_sweep(device, oracle, block):
 def test_culling_sweep(device, oracle, block):
     bad = [s for s in range(5000 + 40 * block, 5040 + 40 * block) if not inside_area_equal(fuzz_cull.case(s), device, oracle)]
     assert not bad, "seeds that differ from the oracle: %s" % bad
+
+
+@pytest.mark.parametrize("seed", [45003])
+def test_soup_seeds_that_once_differed(device, oracle, seed):
+    """45003: no depth test, a sliver clipped by the near and the far plane whose fan triangles overlap after snapping --
+    the last fan triangle submitted owns the pixel, like the last primitive."""
+    assert inside_area_equal(fuzz_soup.case(seed), device, oracle)
