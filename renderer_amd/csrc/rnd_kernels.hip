@@ -1946,7 +1946,10 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     RND_STAMP(fp, stamp, 1); /* rasterisation */
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t ovf = fp.counters[CTR_OVERFLOW];
-        if (ovf) fp.status_host[0] = ovf; /* a list overflowed: the host reports it at the next wait */
+        /* a list overflowed: the host reports it at the next wait.  The flags go out with their complement beside them: the
+         * host takes the pair for a report only when the two agree, so nothing else that might land in that pinned word
+         * reads as one */
+        if (ovf) { fp.status_host[0] = ovf; fp.status_host[1] = ~ovf; }
     }
     __syncthreads();
     /* every thread has read the list length: leave the counter clean for the next frame's binning */
