@@ -9,6 +9,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_cull  # noqa: E402
+import fuzz_shards  # noqa: E402
 import fuzz_soup  # noqa: E402
 from renderer_amd.runner import SceneRunner  # noqa: E402
 
@@ -44,3 +45,23 @@ def test_soup_seeds_that_once_differed(device, oracle, seed):
     """45003: no depth test, a sliver clipped by the near and the far plane whose fan triangles overlap after snapping --
     the last fan triangle submitted owns the pixel, like the last primitive."""
     assert inside_area_equal(fuzz_soup.case(seed), device, oracle)
+
+
+def test_shards_compose_the_frame_sweep(device):
+    """fuzz_shards.py, bounded: soups as interleaved tile shards and instanced scenes as bands, composed, against the
+    same frames rendered whole."""
+    bad = []
+    for seed in range(2000, 2040):
+        n = int(np.random.RandomState(70000 + seed).choice([2, 3, 4, 5, 7, 8]))
+        if seed % 2 == 0:
+            sc = fuzz_soup.case(seed)
+            sc.area = (0, 0, sc.width, sc.height)
+            ok = fuzz_shards.tiles_compose(sc, device, n)
+        else:
+            sc = fuzz_cull.case(seed)
+            sc.area = (0, 0, sc.width, sc.height)
+            sc.scissor = (0, 0, sc.width, sc.height)
+            ok = fuzz_shards.bands_compose(sc, device, n)
+        if not ok:
+            bad.append(seed)
+    assert not bad, "seeds whose shards do not compose the frame: %s" % bad
