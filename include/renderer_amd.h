@@ -228,7 +228,9 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence);
  * allocates.  The buffers, texture, pipeline and target are created beforehand as usual.
  * Limits (beyond them the call fails with RND_ERROR_OUT_OF_DEVICE_MEMORY and draws nothing): vertex_count <= 65 536,
  * index_count / 3 <= 131 072, a target of at most 1024 tiles of 32x32 pixels (1280x720 has 920).  Indices >= vertex_count
- * drop their primitive.  The render area is the whole target.
+ * drop their primitive.  The render area is the whole target.  The static array also holds at most 16 384 fan triangles of
+ * clipped primitives and 32 768 entries of the pass-wide list (primitives over many tiles, spill of full tile lists): a
+ * draw beyond that renders an incomplete frame and the fence's wait reports the overflow, as the recorded path does.
  * Every call on a GPU shares that GPU's array: calls run one after the other on the device's stream, and two devices
  * objects on one GPU (or a caller-supplied stream per device) must not have such calls in flight together. */
 typedef struct rnd_noalloc_draw {
