@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_clip  # noqa: E402
 import fuzz_cull  # noqa: E402
 import fuzz_shards  # noqa: E402
 import fuzz_soup  # noqa: E402
@@ -65,3 +66,11 @@ def test_shards_compose_the_frame_sweep(device):
         if not ok:
             bad.append(seed)
     assert not bad, "seeds whose shards do not compose the frame: %s" % bad
+
+
+def test_clipped_slivers_sweep(device, oracle):
+    """fuzz_clip.py, bounded: soups across both clip planes, nothing culled, every depth mode, one and four samples.  The
+    listed seeds are cases the build before the fan triangles' tie order followed the submission order got wrong."""
+    seeds = [34, 247, 408, 421, 857, 1175, 1328, 3991, 4127, 4717] + list(range(20000, 20030))
+    bad = [s for s in seeds if not inside_area_equal(fuzz_clip.case(s), device, oracle)]
+    assert not bad, "seeds that differ from the oracle: %s" % bad
