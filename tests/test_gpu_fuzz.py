@@ -12,6 +12,7 @@ import fuzz_clip  # noqa: E402
 import fuzz_cull  # noqa: E402
 import fuzz_shards  # noqa: E402
 import fuzz_soup  # noqa: E402
+import fuzz_state  # noqa: E402
 from renderer_amd.runner import SceneRunner  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -73,4 +74,11 @@ def test_clipped_slivers_sweep(device, oracle):
     listed seeds are cases the build before the fan triangles' tie order followed the submission order got wrong."""
     seeds = [34, 247, 408, 421, 857, 1175, 1328, 3991, 4127, 4717] + list(range(20000, 20030))
     bad = [s for s in seeds if not inside_area_equal(fuzz_clip.case(s), device, oracle)]
+    assert not bad, "seeds that differ from the oracle: %s" % bad
+
+
+def test_recorded_state_sweep(device, oracle):
+    """fuzz_state.py, bounded: vertex layouts, shared vertices, buffer offsets, firstIndex and vertexOffset, several
+    pipelines, uniform blocks and textures in one pass, viewports with a depth range, colour formats, clear values."""
+    bad = [s for s in range(60) if not inside_area_equal(fuzz_state.case(s), device, oracle)]
     assert not bad, "seeds that differ from the oracle: %s" % bad
