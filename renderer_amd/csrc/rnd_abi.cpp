@@ -43,6 +43,16 @@ int fail(int code, const std::string& msg)
 
 double srgb_to_linear(double s) { return s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4); }
 
+/* Host memory to device memory, finished on return.  On a named stream and waited for there: what the null stream's
+ * hipMemcpy has done by the time it returns is less plainly said, and a command buffer's non-blocking stream does not
+ * wait for the null stream. */
+hipError_t upload_now(void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+    if (!bytes) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+
 template <typename T>
 struct DeviceArray {
     T* ptr = nullptr;
@@ -54,14 +64,24 @@ struct DeviceArray {
         if (!n) return hipSuccess;
         return hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
     }
-    hipError_t upload(const std::vector<T>& v)
+    hipError_t upload(const std::vector<T>& v, hipStream_t s)
     {
         hipError_t e = resize(v.size());
         if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return upload_now(ptr, v.data(), v.size() * sizeof(T), s);
     }
     void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } count = 0; }
 };
+
+/* Zeroes device memory and returns when it is zero.  hipMemset is ordered on the null stream and may return before
+ * the device has written; a command buffer's stream is non-blocking and does not wait for the null stream, so a kernel
+ * launched on it soon afterwards could still read what the allocation held before (a freed image's words). */
+hipError_t zero_now(void* p, size_t bytes, hipStream_t s)
+{
+    if (!bytes) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
 
 } // namespace
 
@@ -337,10 +357,17 @@ int flush_pending(rnd_device dev)
 int report_overflow(rnd_device dev)
 {
     if (!dev->status_host || !*dev->status_host) return RND_SUCCESS;
-    const uint32_t ovf = *dev->status_host;
+    /* the tile kernel writes the flags and, beside them, their complement */
+    const uint32_t ovf = dev->status_host[0], check = dev->status_host[1];
     memset(dev->status_host, 0, 64);
-    return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, std::string("a work list overflowed while rendering (flags ") + std::to_string(ovf) +
-                "; pass-wide list=1, clipped triangles=4): the frame is incomplete");
+    if (check == ~ovf && !(ovf & ~(OVF_LARGE | OVF_CLIP_TRIS)))
+        return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, std::string("a work list overflowed while rendering (flags ") + std::to_string(ovf) +
+                    "; pass-wide list=1, clipped triangles=4): the frame is incomplete");
+    /* anything else is no report a kernel of this library makes: said as loudly, and with both words, so that whoever
+     * meets it can tell a counter that was read before it was zeroed (the pair agrees) from a stray store (it does not) */
+    char words[96];
+    snprintf(words, sizeof words, "0x%08X / 0x%08X (%s)", ovf, check, check == ~ovf ? "a pair" : "not a pair");
+    return fail(RND_ERROR_DEVICE_LOST, std::string("the status words hold ") + words + ", which is no overflow report: the frame may be incomplete");
 }
 
 /* a colour as the shading kernel stores it: linear -> sRGB code = number of thresholds not above
@@ -545,7 +572,7 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc tables failed");
     }
     /* a failure from here on releases what the device object already holds */
-    hipError_t e = hipMemcpy(dev->tables, &host_tables, sizeof(ShadeTables), hipMemcpyHostToDevice);
+    hipError_t e = upload_now(dev->tables, &host_tables, sizeof(ShadeTables), dev->stream);
     for (int i = 0; i <= RND_STAGE_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&dev->ev[i]);
     if (e == hipSuccess)
         e = hipHostMalloc(reinterpret_cast<void**>(&dev->stage_host), rnd_device_t::STAGE_SLOTS * rnd_device_t::STAGE_SLOT_BYTES, hipHostMallocDefault);
@@ -643,7 +670,7 @@ int rnd_buffer_create(rnd_device dev, uint64_t bytes, uint32_t usage, const void
     uint8_t* p = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), (size_t)bytes));
     if (init) {
-        hipError_t e = hipMemcpy(p, init, (size_t)bytes, hipMemcpyHostToDevice);
+        hipError_t e = upload_now(p, init, (size_t)bytes, dev->stream);
         if (e != hipSuccess) { (void)hipFree(p); return fail(RND_ERROR_DEVICE_LOST, "buffer upload failed"); }
     }
     rnd_buffer b = new rnd_buffer_t{dev, p, bytes, usage};
@@ -740,7 +767,7 @@ int rnd_texture_create_2d(rnd_device dev, uint32_t width, uint32_t height, int32
     std::vector<uint8_t> rgba;
     const uint8_t* src = static_cast<const uint8_t*>(texels);
     if (ch != 4) { expand_rgba(src, ch, (size_t)width * height, rgba); src = rgba.data(); }
-    hipError_t e = hipMemcpy(t->level_ptr[0], src, (size_t)width * height * 4, hipMemcpyHostToDevice);
+    hipError_t e = upload_now(t->level_ptr[0], src, (size_t)width * height * 4, dev->stream);
     if (e != hipSuccess) { rnd_texture_destroy(t); return fail(RND_ERROR_DEVICE_LOST, "texture upload failed"); }
     for (uint32_t l = 1; l < levels; ++l) {
         launch_mip(t->level_ptr[l - 1], level_dim(width, l - 1), level_dim(height, l - 1), t->level_ptr[l], level_dim(width, l),
@@ -767,7 +794,7 @@ int rnd_texture_create_levels(rnd_device dev, uint32_t width, uint32_t height, i
         const uint8_t* src = static_cast<const uint8_t*>(level_texels[l]);
         if (!src) { rnd_texture_destroy(t); return fail(RND_ERROR_INVALID_ARGUMENT, "texture level pointer is null"); }
         if (ch != 4) { expand_rgba(src, ch, texels, rgba); src = rgba.data(); }
-        hipError_t e = hipMemcpy(t->level_ptr[l], src, texels * 4, hipMemcpyHostToDevice);
+        hipError_t e = upload_now(t->level_ptr[l], src, texels * 4, dev->stream);
         if (e != hipSuccess) { rnd_texture_destroy(t); return fail(RND_ERROR_DEVICE_LOST, "texture upload failed"); }
     }
     *out = t;
@@ -823,8 +850,8 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
     hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&t->color), px * 4);
     hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&t->depth), px * samples * 4);
     if (e1 != hipSuccess || e2 != hipSuccess) { rnd_target_destroy(t); return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "hipMalloc target failed"); }
-    (void)hipMemset(t->color, 0, px * 4);
-    (void)hipMemset(t->depth, 0, px * samples * 4);
+    (void)zero_now(t->color, px * 4, dev->stream);
+    (void)zero_now(t->depth, px * samples * 4, dev->stream);
     dev->targets.push_back(t);
     *out = t;
     return RND_SUCCESS;
@@ -1186,7 +1213,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     if (!jobs.empty()) {
         DeviceArray<IndexRangeJob> d_jobs;
         DeviceArray<uint32_t> d_max;
-        HIP_TRY(d_jobs.upload(jobs));
+        HIP_TRY(d_jobs.upload(jobs, dev->stream));
         HIP_TRY(d_max.resize(jobs.size()));
         HIP_TRY(hipMemsetAsync(d_max.ptr, 0, jobs.size() * 4, dev->stream));
         for (size_t b = 0; b < jobs.size(); b += 32768) {
@@ -1230,8 +1257,8 @@ int rnd_cmd_end(rnd_cmd cmd)
                 for (int k = 0; k < 6; ++k) boxes[j * 6 + k] = k < 3 ? 0xFFFFFFFFu : 0u;
             DeviceArray<BoundsJob> d_bjobs;
             DeviceArray<uint32_t> d_boxes;
-            HIP_TRY(d_bjobs.upload(bjobs));
-            HIP_TRY(d_boxes.upload(boxes));
+            HIP_TRY(d_bjobs.upload(bjobs, dev->stream));
+            HIP_TRY(d_boxes.upload(boxes, dev->stream));
             for (size_t b = 0; b < bjobs.size(); b += 32768) {
                 uint32_t cnt = (uint32_t)std::min<size_t>(32768, bjobs.size() - b);
                 launch_bounds(d_bjobs.ptr + b, d_boxes.ptr + b * 6, cnt, dev->stream);
@@ -1297,12 +1324,12 @@ int rnd_cmd_end(rnd_cmd cmd)
     const size_t clip_tri_cap = std::min<size_t>(MAX_FAN * slots, 2 * slots + 65536) + 1;
 
     cmd->release_compiled();
-    HIP_TRY(cmd->d_draws.upload(ds));
+    HIP_TRY(cmd->d_draws.upload(ds, cmd->stream));
     HIP_TRY(cmd->d_derived.resize(n));
-    if (n) HIP_TRY(hipMemset(cmd->d_derived.ptr, 0, n * sizeof(DrawDerived))); /* a draw without vertices is never marked visible */
-    HIP_TRY(cmd->d_vchunks.upload(vchunks));
-    HIP_TRY(cmd->d_tchunks.upload(tchunks));
-    HIP_TRY(cmd->d_textures.upload(td));
+    if (n) HIP_TRY(zero_now(cmd->d_derived.ptr, n * sizeof(DrawDerived), cmd->stream)); /* a draw without vertices is never marked visible */
+    HIP_TRY(cmd->d_vchunks.upload(vchunks, cmd->stream));
+    HIP_TRY(cmd->d_tchunks.upload(tchunks, cmd->stream));
+    HIP_TRY(cmd->d_textures.upload(td, cmd->stream));
     HIP_TRY(cmd->d_svtx.resize((size_t)svtx_total));
     HIP_TRY(cmd->d_svary.resize((size_t)svtx_total));
     HIP_TRY(cmd->d_prim_rec.resize(slots));
@@ -1313,11 +1340,11 @@ int rnd_cmd_end(rnd_cmd cmd)
     HIP_TRY(cmd->d_clip_tris.resize(clip_tri_cap));
     HIP_TRY(cmd->d_counters.resize(CTR_COUNT));
     /* every frame leaves its counters at zero for the next one; the first frame needs them so */
-    HIP_TRY(hipMemset(cmd->d_tile_count.ptr, 0, n_tiles * TILE_COUNT_STRIDE * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(cmd->d_counters.ptr, 0, CTR_COUNT * sizeof(uint32_t)));
+    HIP_TRY(zero_now(cmd->d_tile_count.ptr, n_tiles * TILE_COUNT_STRIDE * sizeof(uint32_t), cmd->stream));
+    HIP_TRY(zero_now(cmd->d_counters.ptr, CTR_COUNT * sizeof(uint32_t), cmd->stream));
 #ifdef RND_PROBES
     HIP_TRY(cmd->d_probe.resize(((size_t)tiles_x * (tiles_y + 8) + 64) * 16 + vchunks.size() / 4 + tchunks.size() / 4 + 64 + 8 * 64)); /* the tile kernel's grid is padded to whole groups of eight rows */
-    HIP_TRY(hipMemset(cmd->d_probe.ptr, 0, cmd->d_probe.count * sizeof(unsigned long long)));
+    HIP_TRY(zero_now(cmd->d_probe.ptr, cmd->d_probe.count * sizeof(unsigned long long), cmd->stream));
 #endif
 
     FrameParams& fp = cmd->fp;

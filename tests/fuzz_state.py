@@ -161,6 +161,10 @@ def main():
         r = SceneRunner(sc, dev)
         try:
             color, depth = r.render()
+        except api.RendererError as e:
+            bad += 1
+            print("seed %d: ERROR %s (%d tris in %d draws, area %s scissor %s)" % (seed, e, sc.triangle_count(), len(sc.draws), sc.area, sc.scissor), flush=True)
+            continue
         finally:
             r.destroy()
         oc, od, _ = oracle.render_scene(sc, threads=8)

@@ -717,3 +717,28 @@ def test_a_device_outlives_what_was_created_on_it():
     assert not fence.h and not dev.h
     fence.destroy()  # a second destroy of either is a no-op
     dev.destroy()
+
+
+def test_a_pass_without_geometry_reads_zeroed_counters(device, oracle):
+    """A pass whose scissor is empty launches no geometry kernel, so nothing but the recording has zeroed the list
+    counters the tile kernel reads: they must be zero by the time the first frame runs, whatever the allocation held
+    before (here the words of a freed target) and whatever else the device was still doing when the pass was recorded
+    (here the mip chain of a large texture)."""
+    big = scenes.checker_texture(2048, 3)
+    for i in range(25):
+        warm = SceneRunner(helpers.soup_scene(256, 256, 300, 100 + i, max_extent=1.5), device)
+        try:
+            warm.render()
+        finally:
+            warm.destroy()
+        texture = api.Texture(device, big, gen_mips=True)
+        sc = helpers.soup_scene(64, 48, 50, i)
+        sc.scissor = (5, 5, 0, 10)
+        r = SceneRunner(sc, device)
+        try:
+            color, depth = r.render()
+        finally:
+            r.destroy()
+            texture.destroy()
+        oc, od, _ = oracle.render_scene(sc, threads=4)
+        assert np.array_equal(depth, od) and np.array_equal(color, oc)
