@@ -336,8 +336,14 @@ int staged_write(rnd_device dev, uint8_t* dst, const void* src, size_t bytes)
     if (dev->stage_used[slot]) HIP_TRY(hipEventSynchronize(dev->stage_ev[slot]));
     uint8_t* staging = dev->stage_host + (size_t)slot * rnd_device_t::STAGE_SLOT_BYTES;
     memcpy(staging, src, bytes);
-    /* frames already queued read the old bytes: the copy follows them */
-    HIP_TRY(follow_frames(dev));
+    /* frames already queued read the old bytes: the copy follows them.  With frames of one or two command buffers in
+     * flight the device's stream waits for them on the GPU; with more, the host waits for the device instead: a copy
+     * queued behind six to eight such waits at once left rnd_device_wait_idle waiting for good now and then
+     * (tests/fuzz_sequence.py), and this is no per-frame path (the per-frame uniform block rides in the kernel arguments) */
+    int in_flight = 0;
+    for (rnd_cmd c : dev->cmds) in_flight += c->own_stream && c->submitted;
+    if (in_flight > 2) HIP_TRY(sync_all(dev));
+    else HIP_TRY(follow_frames(dev));
     HIP_TRY(hipMemcpyAsync(dst, staging, bytes, hipMemcpyHostToDevice, dev->stream));
     HIP_TRY(hipEventRecord(dev->stage_ev[slot], dev->stream));
     dev->stage_used[slot] = true;

@@ -82,3 +82,4 @@ def test_recorded_state_sweep(device, oracle):
     pipelines, uniform blocks and textures in one pass, viewports with a depth range, colour formats, clear values."""
     bad = [s for s in range(60) if not inside_area_equal(fuzz_state.case(s), device, oracle)]
     assert not bad, "seeds that differ from the oracle: %s" % bad
+
