@@ -17,6 +17,10 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(rnd_[a-z0-9_]+)\s*\(", text)))
 
 
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
 def test_header_symbols_are_exported():
     names = declared_symbols()
     assert len(names) >= 40
@@ -44,20 +48,12 @@ def test_vulkan_named_entry_points_are_exported():
         assert b"HIP device" in lib.rndVkLastError()
 
 
-def _has_gpu():
-    return os.path.exists("/dev/kfd")
-
-
 def test_binding_loads_and_types_are_declared():
     lib = _lib.load()
     for n in _lib.SYMBOLS:
         assert getattr(lib, n).argtypes is not None
     assert ctypes.sizeof(_lib.PipelineInfo) == 4 + 3 * 8 + 4 * 10
     assert ctypes.sizeof(_lib.SamplerInfo) == 12
-
-
-def _has_gpu():
-    return os.path.exists("/dev/kfd")
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure path")
