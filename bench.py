@@ -620,7 +620,8 @@ def main():
         # The line's own measurement is taken.  A leg in which one rank fails and the others wait for it in a collective would
         # keep every rank waiting until the process group's own time limit ends them all without a line: every rank therefore
         # carries a timer over the legs (they take well under a minute together), and when it fires rank 0 prints the line
-        # with the leg marked as timed out and every rank ends with status 0.
+        # with the leg marked as timed out and every rank ends with status 3: the line is there, the exit status says
+        # that a leg is not.
         state = {"leg": legs[0][0]}
 
         def give_up():
@@ -628,7 +629,7 @@ def main():
                 out[state["leg"]] = {"error": "timed out after %d s (some rank did not reach a collective)" % LEGS_TIME_LIMIT_S}
                 out["n_gpus"] = world
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         timer = threading.Timer(LEGS_TIME_LIMIT_S, give_up)
         timer.daemon = True
@@ -642,6 +643,12 @@ def main():
             except Exception as e:  # noqa: BLE001 - reported, not hidden
                 if rank == 0:
                     out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                # the other ranks may still be inside this leg's collectives: entering the next leg's would pair
+                # collectives that do not belong together.  Print what there is and end every rank here.
+                if rank == 0:
+                    out["n_gpus"] = world
+                    print(json.dumps(out), flush=True)
+                os._exit(3)
         timer.cancel()
     if rank == 0:
         out["n_gpus"] = dist.get_world_size() if dist is not None else 1

@@ -19,6 +19,8 @@
 #include <string>
 #include <utility>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 using namespace rnd;
@@ -26,6 +28,7 @@ using namespace rnd;
 namespace {
 
 thread_local std::string g_last_error;
+thread_local std::string g_sync_report; /* what a wait with a deadline found (drain_stream); added to the error of the HIP call that failed */
 
 int fail(int code, const std::string& msg)
 {
@@ -38,7 +41,7 @@ int fail(int code, const std::string& msg)
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess)                                                                \
             return fail(e_ == hipErrorOutOfMemory ? RND_ERROR_OUT_OF_DEVICE_MEMORY : RND_ERROR_DEVICE_LOST, \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+                        std::string(#expr) + ": " + hipGetErrorString(e_) + (g_sync_report.empty() ? "" : " -- " + g_sync_report)); \
     } while (0)
 
 double srgb_to_linear(double s) { return s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4); }
@@ -83,6 +86,39 @@ hipError_t zero_now(void* p, size_t bytes, hipStream_t s)
     return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
 
+/* Cross-stream order is an event recorded on the producer's tail and waited for by the consumer.  Every such edge takes
+ * the next event of a small ring kept by the producer, so an event is recorded again only after EDGES other edges of
+ * the same producer have been set up: a wait that is still queued never has its event recorded anew underneath it. */
+struct EventRing {
+    static constexpr unsigned EDGES = 16;
+    hipEvent_t ev[EDGES] = {};
+    unsigned next = 0;
+    hipError_t create()
+    {
+        for (unsigned i = 0; i < EDGES; ++i) {
+            const hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    void destroy() { for (unsigned i = 0; i < EDGES; ++i) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; } }
+    hipEvent_t take() { return ev[next++ % EDGES]; }
+};
+
+/* A stream command buffers execute on.  The device keeps a pool of them, created once and kept until the device is
+ * destroyed; command buffers are dealt to the pool's streams (see rnd_cmd_create). */
+struct CmdStream {
+    hipStream_t stream = nullptr;
+    EventRing done;            /* edges from this stream's tail to a stream that has to follow it */
+    bool submitted = false;    /* work may still be running on the stream */
+    uint64_t seen_seq = 0;     /* the device's upload_seq this stream has been ordered behind */
+    int users = 0;             /* command buffers that execute on it */
+    int index = 0;
+    /* the last cross-stream wait queued on this stream, for the report of a wait that does not end */
+    const char* last_wait = "none";
+    uint64_t last_wait_seq = 0;
+};
+
 } // namespace
 
 struct rnd_device_t {
@@ -113,12 +149,28 @@ struct rnd_device_t {
     /* Frames in flight: every command buffer of a device that owns its stream executes on a
      * stream of its own, so consecutive frames overlap on the GPU like the reference's frames
      * in flight (vk_app.cpp:109-130).  What stays ordered across those streams:
-     *  - work queued on the device's own stream (uploads, copies) precedes later frames (order_ev)
+     *  - work queued on the device's own stream (uploads, copies) precedes later frames (the device's ring of events)
      *    and follows the frames already submitted (their done events);
      *  - frames that render into the same target run one after the other (the target's event). */
     std::vector<rnd_cmd> cmds;
     std::vector<rnd_target> targets;
-    hipEvent_t order_ev = nullptr;
+    /* The streams command buffers execute on: as many as the runtime has hardware queues in one priority pool
+     * less one for the device's own stream (GPU_MAX_HW_QUEUES - 1, 3 unless the environment says otherwise;
+     * RND_CMD_STREAMS overrides), made when the first
+     * command buffers are created and kept for the device's lifetime.  Command buffers beyond that number share a
+     * stream with an earlier one -- ordered by the stream itself -- instead of getting a stream that would share a
+     * hardware queue with another stream behind the runtime's back, where one stream's barrier packets sit in front
+     * of the other's work; and no stream or event is created or destroyed as command buffers come and go. */
+    std::vector<CmdStream*> cmd_streams;
+    int max_cmd_streams = 3;
+    EventRing order;               /* edges from the device's own stream to command buffers' streams */
+    const char* dev_last_wait = "none";
+    /* the last cross-stream edges set up on this device (stream -1: the device's own), for the report of a wait that does not end */
+    struct Edge { int waiter, producer; hipEvent_t ev; const char* why; uint64_t number; };
+    static constexpr int EDGE_LOG = 48;
+    Edge edges[EDGE_LOG] = {};
+    uint64_t edge_count = 0;
+    int debug_sync_ms = 0;         /* RND_DEBUG_SYNC=1: waits for the device poll every stream against a deadline and say which one is stuck */
     uint64_t upload_seq = 0;       /* counts the pieces of work queued on the device's own stream */
     int live_objects = 0;          /* buffers, textures, targets, pipelines, command buffers and fences not yet destroyed: each holds a
                                     * pointer to this object, so the device outlives them (rnd_device_destroy refuses while any is left) */
@@ -157,7 +209,7 @@ struct rnd_target_t {
     int32_t color_format;
     uint8_t* color;
     uint32_t* depth;
-    hipEvent_t order_ev;       /* recorded on last_stream when another stream has to wait for it */
+    EventRing order;           /* edges from last_stream's tail to another stream that renders into the target next */
     hipStream_t last_stream;   /* stream of the last frame rendered into, or copy taken from, this target */
     bool last_valid;
 };
@@ -192,10 +244,8 @@ enum CmdState { CMD_INITIAL, CMD_RECORDING, CMD_IN_PASS, CMD_EXECUTABLE };
 
 struct rnd_cmd_t {
     rnd_device dev = nullptr;
-    hipStream_t stream = nullptr; /* the device's stream, or this command buffer's own */
-    bool own_stream = false;
-    hipEvent_t done_ev = nullptr; /* recorded on the stream's tail when another stream has to wait for it */
-    bool submitted = false;       /* work may still be running on the stream */
+    hipStream_t stream = nullptr; /* the device's stream, or one of the device's pool (cs) */
+    CmdStream* cs = nullptr;      /* null: the command buffer executes on the device's own stream */
     CmdState state = CMD_INITIAL;
     /* pass */
     bool has_pass = false;
@@ -231,7 +281,6 @@ struct rnd_cmd_t {
     uint32_t shard_index = 0, shard_count = 1;
     uint64_t geometry_epoch = 0;   /* the device's when the draws' boxes were computed */
     uint64_t index_epoch = 0;      /* the device's when the draws' index ranges were scanned */
-    uint64_t seen_seq = 0;         /* the device's upload_seq this command buffer's stream has been ordered behind */
 
     void release_compiled()
     {
@@ -295,24 +344,63 @@ int set_device(rnd_device dev)
     return RND_SUCCESS;
 }
 
+/* Waits for one stream.  With a deadline (RND_DEBUG_SYNC=1) the stream is polled instead of waited for, and a stream
+ * that has not drained by then is named in the error with the last cross-stream wait queued on it, rather than the call
+ * never returning. */
+hipError_t drain_stream(rnd_device dev, hipStream_t s, const char* name, int index, const char* last_wait)
+{
+    if (dev->debug_sync_ms <= 0) return hipStreamSynchronize(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > dev->debug_sync_ms) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "%s %d has not drained after %d ms; the last cross-stream wait queued on it: %s.  Streams now:", name, index,
+                     dev->debug_sync_ms, last_wait);
+            g_sync_report = msg;
+            auto state = [](hipError_t q) { return q == hipSuccess ? "idle" : q == hipErrorNotReady ? "busy" : "error"; };
+            g_sync_report += std::string(" device ") + state(hipStreamQuery(dev->stream));
+            for (CmdStream* cs : dev->cmd_streams)
+                g_sync_report += " cs" + std::to_string(cs->index) + " " + state(hipStreamQuery(cs->stream)) + (cs->submitted ? "(submitted)" : "");
+            g_sync_report += ".  Edges (number waiter<-producer event-state why):";
+            const uint64_t first = dev->edge_count > rnd_device_t::EDGE_LOG ? dev->edge_count - rnd_device_t::EDGE_LOG : 0;
+            for (uint64_t k = first; k < dev->edge_count; ++k) {
+                const rnd_device_t::Edge& ed = dev->edges[k % rnd_device_t::EDGE_LOG];
+                snprintf(msg, sizeof msg, " [%llu %d<-%d %s %s]", (unsigned long long)ed.number, ed.waiter, ed.producer,
+                         state(hipEventQuery(ed.ev)), ed.why);
+                g_sync_report += msg;
+            }
+            return hipErrorNotReady;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+
 /* waits for everything queued on the device: its own stream and every command buffer's */
 hipError_t sync_all(rnd_device dev)
 {
-    hipError_t e = hipStreamSynchronize(dev->stream);
-    for (rnd_cmd c : dev->cmds) {
-        if (!c->own_stream) continue;
-        const hipError_t e2 = hipStreamSynchronize(c->stream);
+    g_sync_report.clear();
+    hipError_t e = drain_stream(dev, dev->stream, "the device's stream", 0, dev->dev_last_wait);
+    for (CmdStream* cs : dev->cmd_streams) {
+        if (e == hipErrorNotReady) break; /* a stuck stream has been named: the others are not waited for */
+        const hipError_t e2 = drain_stream(dev, cs->stream, "command-buffer stream", cs->index, cs->last_wait);
         if (e == hipSuccess) e = e2;
     }
-    for (rnd_cmd c : dev->cmds) { c->submitted = false; c->seen_seq = dev->upload_seq; }
+    if (e == hipSuccess) for (CmdStream* cs : dev->cmd_streams) { cs->submitted = false; cs->seen_seq = dev->upload_seq; }
     return e;
 }
 
 /* Cross-stream order is set up where it is needed, not on every submit: the producer's tail is
- * marked with an event at that moment and the waiter waits for it. */
-hipError_t wait_for_stream(hipStream_t waiter, hipStream_t producer, hipEvent_t ev)
+ * marked with an event of the producer's ring at that moment and the waiter waits for it. */
+hipError_t wait_for_stream(rnd_device dev, hipStream_t waiter, int waiter_id, hipStream_t producer, int producer_id, EventRing& ring, const char* why)
 {
     if (waiter == producer) return hipSuccess;
+    const hipEvent_t ev = ring.take();
+    rnd_device_t::Edge& log = dev->edges[dev->edge_count % rnd_device_t::EDGE_LOG];
+    log = {waiter_id, producer_id, ev, why, dev->edge_count};
+    ++dev->edge_count;
     const hipError_t e = hipEventRecord(ev, producer);
     return e != hipSuccess ? e : hipStreamWaitEvent(waiter, ev, 0);
 }
@@ -320,10 +408,11 @@ hipError_t wait_for_stream(hipStream_t waiter, hipStream_t producer, hipEvent_t 
 /* the device's stream waits for every frame already submitted */
 hipError_t follow_frames(rnd_device dev)
 {
-    for (rnd_cmd c : dev->cmds) {
-        if (!c->own_stream || !c->submitted) continue;
-        const hipError_t e = wait_for_stream(dev->stream, c->stream, c->done_ev);
+    for (CmdStream* cs : dev->cmd_streams) {
+        if (!cs->submitted) continue;
+        const hipError_t e = wait_for_stream(dev, dev->stream, -1, cs->stream, cs->index, cs->done, "follow_frames");
         if (e != hipSuccess) return e;
+        dev->dev_last_wait = "the tail of a command-buffer stream (follow_frames)";
     }
     return hipSuccess;
 }
@@ -336,14 +425,8 @@ int staged_write(rnd_device dev, uint8_t* dst, const void* src, size_t bytes)
     if (dev->stage_used[slot]) HIP_TRY(hipEventSynchronize(dev->stage_ev[slot]));
     uint8_t* staging = dev->stage_host + (size_t)slot * rnd_device_t::STAGE_SLOT_BYTES;
     memcpy(staging, src, bytes);
-    /* frames already queued read the old bytes: the copy follows them.  With frames of one or two command buffers in
-     * flight the device's stream waits for them on the GPU; with more, the host waits for the device instead: a copy
-     * queued behind six to eight such waits at once left rnd_device_wait_idle waiting for good now and then
-     * (tests/fuzz_sequence.py), and this is no per-frame path (the per-frame uniform block rides in the kernel arguments) */
-    int in_flight = 0;
-    for (rnd_cmd c : dev->cmds) in_flight += c->own_stream && c->submitted;
-    if (in_flight > 2) HIP_TRY(sync_all(dev));
-    else HIP_TRY(follow_frames(dev));
+    /* frames already queued read the old bytes: the copy follows them, on the GPU (the host does not wait) */
+    HIP_TRY(follow_frames(dev));
     HIP_TRY(hipMemcpyAsync(dst, staging, bytes, hipMemcpyHostToDevice, dev->stream));
     HIP_TRY(hipEventRecord(dev->stage_ev[slot], dev->stream));
     dev->stage_used[slot] = true;
@@ -362,10 +445,12 @@ int flush_pending(rnd_device dev)
 
 int report_overflow(rnd_device dev)
 {
-    if (!dev->status_host || !*dev->status_host) return RND_SUCCESS;
-    /* the tile kernel writes the flags and, beside them, their complement */
-    const uint32_t ovf = dev->status_host[0], check = dev->status_host[1];
-    memset(dev->status_host, 0, 64);
+    if (!dev->status_host) return RND_SUCCESS;
+    /* the tile kernel writes the flags and, beside them, their complement, as one 64-bit word: read as one */
+    const uint64_t pair = __atomic_load_n(reinterpret_cast<const uint64_t*>(dev->status_host), __ATOMIC_ACQUIRE);
+    if (!pair) return RND_SUCCESS;
+    const uint32_t ovf = (uint32_t)pair, check = (uint32_t)(pair >> 32);
+    __atomic_store_n(reinterpret_cast<uint64_t*>(dev->status_host), (uint64_t)0, __ATOMIC_RELEASE);
     if (check == ~ovf && !(ovf & ~(OVF_LARGE | OVF_CLIP_TRIS)))
         return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, std::string("a work list overflowed while rendering (flags ") + std::to_string(ovf) +
                     "; pass-wide list=1, clipped triangles=4): the frame is incomplete");
@@ -543,9 +628,30 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         return fail(RND_ERROR_INITIALIZATION_FAILED, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     rnd_device dev = new rnd_device_t();
     dev->ordinal = hip_ordinal;
+    /* The runtime keeps one pool of hardware queues per stream priority (GPU_MAX_HW_QUEUES of them each, 4 unless the
+     * environment says otherwise) and lets streams share a queue once a pool is used up; two command buffers on one
+     * queue run one after the other instead of side by side (measured: three frames in flight 53 us per frame with
+     * a shared queue, 43 us without).  The default stream and whatever streams the application makes fill the pool of
+     * normal priority, so this library's streams take the pool of the lowest priority, which nothing else in a process
+     * normally uses, and a collective or copy issued at normal priority beside them is not kept waiting by a frame.
+     *
+     * ALL of the library's streams are of that one priority, the device's own included.  The streams wait for one
+     * another on the GPU (a copy into a uniform buffer follows the frames in flight, later frames follow the copy), and
+     * a hardware queue parked in such a wait still counts as ready work for the queue scheduler: with the device's
+     * stream at normal priority and the command buffers' at the lowest, a wait of the former for a frame of the latter
+     * kept that frame's queue from ever being served, and the wait never ended (with the command buffers at high
+     * priority the other way round: their waits starved the copy they were waiting for).  Among queues of one
+     * priority no wait starves what it waits for.  RND_STREAM_PRIORITY=high or =normal chooses another pool, for all
+     * of them. */
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        const char* pr = getenv("RND_STREAM_PRIORITY");
+        dev->cmd_stream_priority = !pr || !strcmp(pr, "low") ? least : !strcmp(pr, "high") ? greatest : 0;
+    }
     if (stream) { dev->stream = static_cast<hipStream_t>(stream); dev->own_stream = false; }
     else {
-        hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
+        hipError_t e = hipStreamCreateWithPriority(&dev->stream, hipStreamNonBlocking, dev->cmd_stream_priority);
         if (e != hipSuccess) { delete dev; return fail(RND_ERROR_DEVICE_LOST, "hipStreamCreate failed"); }
         dev->own_stream = true;
     }
@@ -590,22 +696,22 @@ int rnd_device_create(int hip_ordinal, void* stream, rnd_device* out)
         e = hipHostGetDevicePointer(&dp, dev->status_host, 0);
         dev->status_dev = static_cast<uint32_t*>(dp);
     }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&dev->order_ev, hipEventDisableTiming);
-    /* The runtime keeps one pool of hardware queues per stream priority (GPU_MAX_HW_QUEUES of them each, 4 unless the
-     * environment says otherwise) and lets streams share a queue once a pool is used up; two command buffers on one
-     * queue run one after the other instead of side by side (measured: three frames in flight 53 us per frame with
-     * a shared queue, 43 us without).  The default stream, this device's own stream and whatever streams the
-     * application makes fill the pool of normal priority, so the command buffers' streams take the pool of the lowest
-     * priority, which nothing else in a process normally uses: up to GPU_MAX_HW_QUEUES command buffers then have a
-     * queue each, and a collective or copy issued at normal priority beside them is not kept waiting by a frame.
-     * RND_STREAM_PRIORITY=high or =normal chooses another pool. */
-    {
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-        const char* pr = getenv("RND_STREAM_PRIORITY");
-        dev->cmd_stream_priority = !pr || !strcmp(pr, "low") ? least : !strcmp(pr, "high") ? greatest : 0;
-    }
+    if (e == hipSuccess) e = dev->order.create();
     if (const char* wg = getenv("RND_TILE_WORKGROUPS")) dev->four_tile_workgroups = atoi(wg) == 4;
+    {
+        /* as many command-buffer streams as one priority pool has hardware queues, less the one the device's own
+         * stream takes (RND_CMD_STREAMS sets the number itself) */
+        int n_cs = 3;
+        if (const char* q = getenv("RND_CMD_STREAMS")) n_cs = atoi(q);
+        else if (const char* hq = getenv("GPU_MAX_HW_QUEUES")) n_cs = atoi(hq) - 1;
+        dev->max_cmd_streams = n_cs < 1 ? 1 : n_cs > 32 ? 32 : n_cs;
+        if (const char* ds = getenv("RND_DEBUG_SYNC")) {
+            if (atoi(ds) > 0) {
+                const char* ms = getenv("RND_DEBUG_SYNC_MS");
+                dev->debug_sync_ms = ms && atoi(ms) > 0 ? atoi(ms) : 20000;
+            }
+        }
+    }
     /* every GPU holds its own copy of the static scratch array at its own address: asked for once per device, here,
      * with that device current */
     if (e == hipSuccess) { void* sp = nullptr; e = noalloc_scratch_address(&sp); dev->scratch = static_cast<uint8_t*>(sp); }
@@ -628,7 +734,13 @@ int rnd_device_destroy(rnd_device dev)
                     " object(s) created on this device are still alive; destroy them first (the device is left as it is)");
     (void)hipSetDevice(dev->ordinal);
     (void)sync_all(dev);
-    if (dev->order_ev) (void)hipEventDestroy(dev->order_ev);
+    dev->order.destroy();
+    for (CmdStream* cs : dev->cmd_streams) {
+        cs->done.destroy();
+        if (cs->stream) (void)hipStreamDestroy(cs->stream);
+        delete cs;
+    }
+    dev->cmd_streams.clear();
     if (dev->tables) (void)hipFree(dev->tables);
     for (int i = 0; i <= RND_STAGE_COUNT; ++i) if (dev->ev[i]) (void)hipEventDestroy(dev->ev[i]);
     for (int i = 0; i < rnd_device_t::STAGE_SLOTS; ++i) if (dev->stage_ev[i]) (void)hipEventDestroy(dev->stage_ev[i]);
@@ -849,8 +961,8 @@ int rnd_target_create(rnd_device dev, uint32_t width, uint32_t height, int32_t c
     if (depth_format != RND_FORMAT_D24_UNORM_S8_UINT) return fail(RND_ERROR_FORMAT_NOT_SUPPORTED, "depth format must be D24_UNORM_S8_UINT");
     if (samples != 1 && samples != 4) return fail(RND_ERROR_FEATURE_NOT_PRESENT, "sample count must be 1 or 4");
     if (int r = set_device(dev)) return r;
-    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, nullptr, nullptr, false};
-    if (hipEventCreateWithFlags(&t->order_ev, hipEventDisableTiming) != hipSuccess) { delete t; return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed"); }
+    rnd_target t = new rnd_target_t{dev, width, height, samples, color_format, nullptr, nullptr, EventRing(), nullptr, false};
+    if (t->order.create() != hipSuccess) { t->order.destroy(); delete t; return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed"); }
     ++dev->live_objects; /* from here on rnd_target_destroy releases it, on the failure paths below too */
     size_t px = (size_t)width * height;
     hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&t->color), px * 4);
@@ -908,7 +1020,7 @@ int rnd_target_destroy(rnd_target target)
     if (!target) return RND_SUCCESS;
     (void)hipSetDevice(target->dev->ordinal);
     (void)sync_all(target->dev);
-    if (target->order_ev) (void)hipEventDestroy(target->order_ev);
+    target->order.destroy();
     { auto& list = target->dev->targets; list.erase(std::remove(list.begin(), list.end(), target), list.end()); }
     if (target->color) (void)hipFree(target->color);
     if (target->depth) (void)hipFree(target->depth);
@@ -964,15 +1076,29 @@ int rnd_cmd_create(rnd_device dev, rnd_cmd* out)
     c->dev = dev;
     c->stream = dev->stream;
     if (dev->own_stream) {
-        /* a caller-supplied stream keeps everything on that stream; otherwise frames of different
-         * command buffers may overlap, each on its own stream */
-        if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, dev->cmd_stream_priority) != hipSuccess) { delete c; return fail(RND_ERROR_DEVICE_LOST, "hipStreamCreate failed"); }
-        c->own_stream = true;
-    }
-    if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) {
-        if (c->own_stream) (void)hipStreamDestroy(c->stream);
-        delete c;
-        return fail(RND_ERROR_DEVICE_LOST, "hipEventCreate failed");
+        /* a caller-supplied stream keeps everything on that stream; otherwise frames of different command buffers
+         * may overlap: the command buffer takes a stream of the device's pool that no other uses, a new one while
+         * the pool is not full, else the one with the fewest users */
+        CmdStream* pick = nullptr;
+        for (CmdStream* cs : dev->cmd_streams) if (cs->users == 0) { pick = cs; break; }
+        if (!pick && (int)dev->cmd_streams.size() < dev->max_cmd_streams) {
+            pick = new CmdStream();
+            pick->index = (int)dev->cmd_streams.size();
+            hipError_t e = hipStreamCreateWithPriority(&pick->stream, hipStreamNonBlocking, dev->cmd_stream_priority);
+            if (e == hipSuccess) e = pick->done.create();
+            if (e != hipSuccess) {
+                pick->done.destroy();
+                if (pick->stream) (void)hipStreamDestroy(pick->stream);
+                delete pick; delete c;
+                return fail(RND_ERROR_DEVICE_LOST, std::string("cmd_create: making a stream failed: ") + hipGetErrorString(e));
+            }
+            pick->seen_seq = 0; /* nothing queued on the device's stream has been waited for yet */
+            dev->cmd_streams.push_back(pick);
+        }
+        if (!pick) for (CmdStream* cs : dev->cmd_streams) if (!pick || cs->users < pick->users) pick = cs;
+        ++pick->users;
+        c->cs = pick;
+        c->stream = pick->stream;
     }
     dev->cmds.push_back(c);
     ++dev->live_objects;
@@ -1390,14 +1516,10 @@ int rnd_cmd_destroy(rnd_cmd cmd)
     if (!cmd) return RND_SUCCESS;
     (void)hipSetDevice(cmd->dev->ordinal);
     (void)sync_all(cmd->dev);
-    if (cmd->own_stream)
-        for (rnd_target t : cmd->dev->targets)
-            if (t->last_stream == cmd->stream) t->last_valid = false; /* all finished; the stream goes away */
+    if (cmd->cs) --cmd->cs->users; /* the stream stays in the device's pool */
     cmd->release_compiled();
     auto& list = cmd->dev->cmds;
     list.erase(std::remove(list.begin(), list.end(), cmd), list.end());
-    if (cmd->done_ev) (void)hipEventDestroy(cmd->done_ev);
-    if (cmd->own_stream) (void)hipStreamDestroy(cmd->stream);
     --cmd->dev->live_objects;
     delete cmd;
     return RND_SUCCESS;
@@ -1426,14 +1548,20 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
 #endif
     hipStream_t s = cmd->stream;
     rnd_target tg = cmd->target;
-    if (s != dev->stream && cmd->seen_seq != dev->upload_seq) {
-        /* uploads and copies queued on the device's stream come first.  Every command buffer has a stream of
-         * its own, so each one waits for what it has not been ordered behind yet, not only the first to submit. */
-        HIP_TRY(hipEventRecord(dev->order_ev, dev->stream));
-        HIP_TRY(hipStreamWaitEvent(s, dev->order_ev, 0));
-        cmd->seen_seq = dev->upload_seq;
+    if (cmd->cs && cmd->cs->seen_seq != dev->upload_seq) {
+        /* uploads and copies queued on the device's stream come first.  Each stream of the pool waits for what it
+         * has not been ordered behind yet, not only the first to submit. */
+        HIP_TRY(wait_for_stream(dev, s, cmd->cs->index, dev->stream, -1, dev->order, "uploads before a frame"));
+        cmd->cs->seen_seq = dev->upload_seq;
+        cmd->cs->last_wait = "the tail of the device's stream (uploads and copies before this frame)";
     }
-    if (tg && tg->last_valid) HIP_TRY(wait_for_stream(s, tg->last_stream, tg->order_ev));
+    if (tg && tg->last_valid && tg->last_stream != s) {
+        int producer_id = -1;
+        for (CmdStream* cs : dev->cmd_streams) if (cs->stream == tg->last_stream) producer_id = cs->index;
+        HIP_TRY(wait_for_stream(dev, s, cmd->cs ? cmd->cs->index : -1, tg->last_stream, producer_id, tg->order, "the target's last frame"));
+        if (cmd->cs) cmd->cs->last_wait = "the last frame or copy of this frame's target, on another stream";
+        else dev->dev_last_wait = "the last frame or copy of a frame's target, on another stream";
+    }
     const bool prof = dev->profiling;
     if (prof) HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_VERTEX], s));
     launch_vertex(fp, dev->pending, s); /* the pending uniform write stays pending: later frames carry it too */
@@ -1443,8 +1571,8 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     launch_tile(fp, s, dev->four_tile_workgroups && fp.samples == 1 ? TILE_LDS_PAD_FOUR : 0u);
     if (prof) { HIP_TRY(hipEventRecord(dev->ev[RND_STAGE_COUNT], s)); dev->stage_valid = true; }
     HIP_TRY(hipGetLastError());
-    if (cmd->own_stream) {
-        cmd->submitted = true;
+    if (cmd->cs) {
+        cmd->cs->submitted = true;
         if (tg) { tg->last_stream = s; tg->last_valid = true; }
     }
     if (fence) {

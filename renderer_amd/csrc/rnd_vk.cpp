@@ -138,7 +138,9 @@ VkResult rndVkCreateDevice(int hip_ordinal, VkDevice* pDevice, VkQueue* pGraphic
 void rndVkDestroyDevice(VkDevice device)
 {
     if (!device) return;
-    rnd_device_destroy(device->dev);
+    /* the library refuses to destroy a device that objects still point at: then the wrapper stays too (the handle
+     * remains valid for destroying those objects) and rndVkLastError says why */
+    if (rnd_device_destroy(device->dev) != RND_SUCCESS) { (void)fail(VK_ERROR_INITIALIZATION_FAILED, std::string("rndVkDestroyDevice: ") + rnd_last_error()); return; }
     delete device; /* the queue and allocator objects are a few bytes each and die with the process */
 }
 

@@ -83,3 +83,28 @@ def test_recorded_state_sweep(device, oracle):
     bad = [s for s in range(60) if not inside_area_equal(fuzz_state.case(s), device, oracle)]
     assert not bad, "seeds that differ from the oracle: %s" % bad
 
+
+
+@pytest.mark.parametrize("seed", [0, 2, 5, 7, 11])
+def test_sequences_of_interleaved_submits(oracle, seed):
+    """fuzz_sequence.py, five fixed sequences: several recorded scenes alive on one device, one to three frames in flight
+    each, submits interleaved without waiting, uniform blocks of different buffers rewritten between submits (each such
+    write makes the device's stream follow every frame in flight), scenes recorded again.  Sequences 2 and 7 are the ones
+    that once never came back from rnd_device_wait_idle.  The device is made with RND_DEBUG_SYNC=1: a stream that does not
+    drain is reported by name instead of the call blocking."""
+    import fuzz_sequence
+    from renderer_amd import api
+    kept = {k: os.environ.get(k) for k in ("RND_DEBUG_SYNC", "RND_DEBUG_SYNC_MS")}
+    os.environ["RND_DEBUG_SYNC"] = "1"
+    os.environ["RND_DEBUG_SYNC_MS"] = "30000"
+    try:
+        dev = api.Device(0)
+    finally:
+        for k, v in kept.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    bad = fuzz_sequence.run(seed, dev)  # a stream reported stuck raises here: the device is then left alone, not destroyed (destroying waits for it)
+    dev.destroy()
+    assert not bad, "images that differ from the oracle: %s" % bad

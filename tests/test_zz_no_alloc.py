@@ -79,6 +79,43 @@ def test_noalloc_draw_equals_recorded_pass(device):
         assert np.array_equal(gc, ec), "scene %d: colour differs at %d bytes" % (k, int((gc != ec).sum()))
 
 
+def _free_device_bytes():
+    """hipMemGetInfo of the current device, from the HIP runtime the library itself is linked against."""
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_noalloc_calls_leave_free_memory_unchanged(device):
+    """What the entry point is for: after one warm-up call (the runtime loads the kernels' code object on first launch)
+    a run of calls takes no device memory -- the free bytes hipMemGetInfo reports are the same before and after."""
+    lib = _lib.load()
+    sc = scenes.config1(320, 200, quads=60, tex_size=64)
+    r = SceneRunner(sc, device)
+    try:
+        d = _lib.NoAllocDraw()
+        ubo = np.ascontiguousarray(sc.ubos[0], dtype=np.float32)
+        push = np.ascontiguousarray(sc.draws[0]["push"], dtype=np.float32)
+        d.target = r.target.h; d.pipeline = r.pipelines[0].h; d.texture = r.textures[0].h
+        d.vertex_buffer = r.vbs[0].h; d.vertex_count = sc.vbs[0].shape[0]
+        d.index_buffer = r.ibs[0].h; d.index_count = sc.ibs[0].size
+        d.uniform_block = ubo.ctypes.data_as(C.POINTER(C.c_float))
+        d.push_constants = push.ctypes.data_as(C.POINTER(C.c_float))
+        d.clear_color = (C.c_float * 4)(*sc.clear_color); d.clear_depth = sc.clear_depth
+        d.viewport = (C.c_float * 6)(*sc.viewport); d.scissor = (C.c_int32 * 4)(*sc.scissor)
+        assert lib.rnd_draw_indexed_noalloc(device.h, C.byref(d), None) == 0, lib.rnd_last_error()
+        device.wait_idle()
+        before = _free_device_bytes()
+        for _ in range(20):
+            assert lib.rnd_draw_indexed_noalloc(device.h, C.byref(d), None) == 0, lib.rnd_last_error()
+        device.wait_idle()
+        after = _free_device_bytes()
+        assert after == before, "20 calls changed the device's free memory by %d bytes" % (before - after)
+    finally:
+        r.destroy()
+
+
 def test_noalloc_limits_are_refused(device):
     lib = _lib.load()
     sc = scenes.config1(200, 120, quads=24, tex_size=32)
