@@ -528,15 +528,17 @@ uint32_t host_depth24(float z)
  * viewport and scissor, the clear values and the depth state -- as opposed to its draws.  Shared by command recording
  * and by the entry point that allocates nothing. */
 void pass_params(FrameParams& fp, rnd_device dev, rnd_target tg, const int32_t area[4], bool has_viewport_and_scissor, const float* vp,
-                 const int32_t* scissor, const float* clear_color, float clear_depth, int depth_test, int depth_less)
+                 const int32_t* scissor, const float* clear_color, float clear_depth, int depth_test, int depth_less, uint32_t tile_h)
 {
+    fp.tile_h = tile_h;
+    fp.tile_h_magic = (uint32_t)((0x100000000ull + tile_h - 1) / tile_h); /* exact for rows below 2^16: row * (magic * tile_h - 2^32) stays below 2^32 */
     fp.status_host = dev->status_dev;
     fp.color = tg->color; fp.depth = tg->depth;
     fp.tables = dev->tables;
     fp.width = tg->width; fp.height = tg->height; fp.samples = tg->samples;
     fp.color_srgb = format_is_srgb(tg->color_format) ? 1u : 0u;
     fp.color_bgra = (tg->color_format == RND_FORMAT_B8G8R8A8_SRGB || tg->color_format == RND_FORMAT_B8G8R8A8_UNORM) ? 1u : 0u;
-    fp.tiles_x = (tg->width + TILE_W - 1) / TILE_W; fp.tiles_y = (tg->height + TILE_H - 1) / TILE_H;
+    fp.tiles_x = (tg->width + TILE_W - 1) / TILE_W; fp.tiles_y = (tg->height + tile_h - 1) / tile_h;
     fp.shard_index = 0; fp.shard_count = 1;
     fp.area_x0 = area[0]; fp.area_y0 = area[1];
     fp.area_x1 = area[0] + area[2] - 1; fp.area_y1 = area[1] + area[3] - 1;
@@ -545,8 +547,8 @@ void pass_params(FrameParams& fp, rnd_device dev, rnd_target tg, const int32_t a
         const int64_t ax0 = std::max<int64_t>(fp.area_x0, 0), ay0 = std::max<int64_t>(fp.area_y0, 0);
         const int64_t ax1 = std::min<int64_t>(fp.area_x1, (int64_t)tg->width - 1), ay1 = std::min<int64_t>(fp.area_y1, (int64_t)tg->height - 1);
         if (ax0 <= ax1 && ay0 <= ay1) {
-            fp.grid_x0 = (uint32_t)(ax0 / TILE_W); fp.grid_y0 = (uint32_t)(ay0 / TILE_H);
-            fp.grid_w = (uint32_t)(ax1 / TILE_W) - fp.grid_x0 + 1; fp.grid_h = (uint32_t)(ay1 / TILE_H) - fp.grid_y0 + 1;
+            fp.grid_x0 = (uint32_t)(ax0 / TILE_W); fp.grid_y0 = (uint32_t)(ay0 / tile_h);
+            fp.grid_w = (uint32_t)(ax1 / TILE_W) - fp.grid_x0 + 1; fp.grid_h = (uint32_t)(ay1 / tile_h) - fp.grid_y0 + 1;
         }
     }
     fp.cull_lo_x = fp.cull_lo_y = -INFINITY; fp.cull_hi_x = fp.cull_hi_y = INFINITY;
@@ -1258,6 +1260,13 @@ int rnd_cmd_set_tile_shard(rnd_cmd cmd, uint32_t shard_index, uint32_t shard_cou
 {
     if (!cmd || !shard_count || shard_index >= shard_count) return fail(RND_ERROR_INVALID_ARGUMENT, "set_tile_shard: bad arguments");
     cmd->shard_index = shard_index; cmd->shard_count = shard_count;
+    /* interleaved shards count tiles of 32 rows: a command buffer already compiled with taller tiles is compiled again */
+    if (shard_count != 1 && cmd->state == CMD_EXECUTABLE && cmd->fp.tile_h != (uint32_t)TILE_H) {
+        if (int r = set_device(cmd->dev)) return r;
+        HIP_TRY(sync_all(cmd->dev));
+        cmd->state = CMD_RECORDING;
+        return rnd_cmd_end(cmd);
+    }
     return RND_SUCCESS;
 }
 
@@ -1442,7 +1451,22 @@ int rnd_cmd_end(rnd_cmd cmd)
         td[k].filter_linear = t->sampler.filtering == RND_FILTER_NEAREST ? 0u : 1u;
     }
 
-    const uint32_t tiles_x = (tg->width + TILE_W - 1) / TILE_W, tiles_y = (tg->height + TILE_H - 1) / TILE_H;
+    /* Rows per tile.  Taller tiles mean fewer workgroups to start and a shorter second round of them, but 40 rows of
+     * sample words leave LDS for four workgroups on a CU instead of five.  Measured, 32 rows against 40: the one-draw
+     * mesh at 1920x1080 with a triangle per two pixels 41.1 -> 40.1 us; the 4K pass of 10 000 small draws 250 -> 258 us;
+     * the mesh of five triangles per pixel 133.9 -> 139.7 us; 1280x720 13.3 -> 14.5 us.  So 40 rows only for a pass that
+     * is one draw (a mesh: triangles of one size all over the target) on a target of 1080p or more with at most two
+     * triangles per pixel; RND_TILE_HEIGHT=32|40 overrides.  A command buffer whose frame is divided among devices by
+     * interleaved tiles keeps the 32 rows its peers' composition counts on. */
+    uint32_t tile_h = TILE_H;
+    {
+        const uint64_t pixels = (uint64_t)tg->width * tg->height;
+        const char* th = getenv("RND_TILE_HEIGHT");
+        if (th && (atoi(th) == TILE_H || atoi(th) == TILE_H_TALL)) tile_h = (uint32_t)atoi(th);
+        else if (n == 1 && pixels >= 1920ull * 1080ull && prim_total <= 2 * pixels) tile_h = TILE_H_TALL;
+        if (tg->samples != 1 || cmd->shard_count != 1) tile_h = TILE_H;
+    }
+    const uint32_t tiles_x = (tg->width + TILE_W - 1) / TILE_W, tiles_y = (tg->height + tile_h - 1) / tile_h;
     const size_t n_tiles = (size_t)tiles_x * tiles_y;
     const size_t slots = tchunks.size() * CHUNK;
     if (slots > SLOT_MASK) return fail(RND_ERROR_OUT_OF_DEVICE_MEMORY, "pass holds more than 2^28 primitive slots");
@@ -1494,7 +1518,7 @@ int rnd_cmd_end(rnd_cmd cmd)
     fp.n_draws = (uint32_t)n; fp.n_vchunks = (uint32_t)vchunks.size(); fp.n_tchunks = (uint32_t)tchunks.size();
     fp.n_textures = (uint32_t)td.size();
     pass_params(fp, dev, tg, cmd->area, cmd->has_viewport && cmd->has_scissor, cmd->viewport, cmd->scissor, cmd->clear_color, cmd->clear_depth,
-                depth_test, depth_less);
+                depth_test, depth_less, tile_h);
     /* an empty rectangle takes no fragment: the geometry kernels are not launched at all (the tile kernel
      * still clears the render area) */
     if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
@@ -1657,7 +1681,7 @@ int rnd_draw_indexed_noalloc(rnd_device dev, const rnd_noalloc_draw* dr, rnd_fen
     fp.direct_index = 1u; fp.direct_ib = d.ib; fp.direct_svtx_base = d.svtx_base;
     const int depth_test = pi.depth_test ? 1 : 0, depth_less = (pi.depth_test && pi.depth_compare == RND_COMPARE_LESS) ? 1 : 0;
     const int32_t area[4] = {0, 0, (int32_t)tg->width, (int32_t)tg->height};
-    pass_params(fp, dev, tg, area, true, vp, dr->scissor, dr->clear_color, dr->clear_depth, depth_test, depth_less);
+    pass_params(fp, dev, tg, area, true, vp, dr->scissor, dr->clear_color, dr->clear_depth, depth_test, depth_less, TILE_H);
     if (fp.clamp_x0 > fp.clamp_x1 || fp.clamp_y0 > fp.clamp_y1) fp.n_vchunks = fp.n_tchunks = 0;
     fp.pass_shader = d.shader;
     fp.pass_texture = d.texture;

@@ -11,12 +11,12 @@
 namespace rnd {
 
 constexpr int TILE_W = 32;           /* pixels per tile side: one workgroup owns a tile's depth/owner words in LDS */
-#ifndef TILE_H_PX
-#define TILE_H_PX 32
-#endif
-constexpr int TILE_H = TILE_H_PX;    /* a multiple of 8: every thread of a tile's workgroup shades TILE_H / 8 pixels */
+/* Rows of pixels per tile: chosen per pass (FrameParams::tile_h; the rule is in rnd_cmd_end), a multiple of 8 -- every
+ * thread of a tile's workgroup shades tile_h / 8 pixels.  32 is the rule, 40 the choice for a one-draw mesh on a large target. */
+constexpr int TILE_H = 32;
+constexpr int TILE_H_TALL = 40;
 constexpr int TILE_SHIFT = 5;        /* log2(TILE_W) */
-constexpr int TILE_PIXELS = TILE_W * TILE_H;
+constexpr int TILE_PIXELS_MAX = TILE_W * TILE_H_TALL;
 #ifndef TILE_THREADS_N
 #define TILE_THREADS_N 256
 #endif
@@ -234,6 +234,8 @@ struct FrameParams {
     uint32_t width, height, samples;
     uint32_t color_srgb, color_bgra;
     uint32_t tiles_x, tiles_y;
+    uint32_t tile_h;         /* rows of pixels per tile: TILE_H or TILE_H_TALL */
+    uint32_t tile_h_magic;   /* ceil(2^32 / tile_h): a pixel row's row of tiles is the high word of row * magic (rows stay below 2^16) */
     uint32_t shard_index, shard_count;
     uint32_t grid_x0, grid_y0, grid_w, grid_h; /* the tiles the render area touches: only these are launched */
     /* Draw culling: the clamp rectangle grown by one pixel, in normalised device coordinates.  A draw whose
@@ -285,6 +287,7 @@ struct NoAllocLayout {
     static constexpr size_t clip_tris = large_list + (size_t)NA_LARGE_CAPACITY * sizeof(LargeEntry);
     static constexpr size_t total = clip_tris + (size_t)NA_CLIP_TRI_CAPACITY * sizeof(ClipTri);
 };
+static_assert(sizeof(DrawStatic) <= 256 && sizeof(DrawDerived) <= 256, "a draw's two records each fit the 256-byte slot NoAllocLayout gives them");
 static_assert(NoAllocLayout::total % 256 == 0 && NoAllocLayout::total < (size_t(32) << 20), "the static scratch array stays under 32 MiB");
 
 /* this device's address of the static scratch array (hipGetSymbolAddress; the current device's copy) */

@@ -61,9 +61,9 @@ __device__ __forceinline__ uint32_t pack_bbox(int tx0, int ty0, int tx1, int ty1
     return (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
 }
 
-/* row of tiles of pixel row y, which pixel_box has clamped to the target (never negative): an unsigned division, one
- * shift for the usual tile height, where the signed one rounds toward zero in three instructions */
-__device__ __forceinline__ int tile_row(int y) { return (int)((uint32_t)y / (uint32_t)TILE_H); }
+/* row of tiles of pixel row y, which pixel_box has clamped to the target (never negative, below 2^16): the division by
+ * the pass's tile height as the high word of one multiplication (FrameParams::tile_h_magic) */
+__device__ __forceinline__ int tile_row(const FrameParams& fp, int y) { return (int)__umulhi((uint32_t)y, fp.tile_h_magic); }
 
 /* primitive slot -> draw, triangle */
 __device__ __forceinline__ void slot_to_prim(const FrameParams& fp, uint32_t slot, uint32_t& draw, uint32_t& tri)
@@ -601,7 +601,7 @@ __device__ __forceinline__ void clip_primitive(const FrameParams& fp, const Draw
         fp.clip_tris[idx] = ct;
         if (vis) {
             TileEntry e = {idx, 0u, 0u, slot | ((uint32_t)(k - 1) << ENTRY_SUB_SHIFT) | FLAG_CLIPPED};
-            bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, tile_row(y0), x1 >> TILE_SHIFT, tile_row(y1)));
+            bin_one(fp, e, pack_bbox(x0 >> TILE_SHIFT, tile_row(fp, y0), x1 >> TILE_SHIFT, tile_row(fp, y1)));
         }
     }
 }
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
             int x0, y0, x1, y1;
             if (setup_tri(t, d.cull_mode, d.front_face) && pixel_box(fp, t, x0, y0, x1, y1)) {
                 valid = true;
-                box = pack_bbox(x0 >> TILE_SHIFT, tile_row(y0), x1 >> TILE_SHIFT, tile_row(y1));
+                box = pack_bbox(x0 >> TILE_SHIFT, tile_row(fp, y0), x1 >> TILE_SHIFT, tile_row(fp, y1));
                 const uint32_t v0 = svtx_base + pf.idx[0], v1 = svtx_base + pf.idx[1], v2 = svtx_base + pf.idx[2];
                 /* what shading needs, in the primitive's own corner order */
                 PrimRec pr = {v0, v1, v2, c.draw};
@@ -788,7 +788,7 @@ struct WalkSetup {
     int32_t sy0, sy1, sy2;  /* one pixel down */
     float z0, gz1, gz2;
     uint32_t pay_lo, pay_hi;
-    uint32_t box;           /* bits 0..4 first column in the tile, 5..9 first row, 10..14 width - 1, 15..19 height - 1, 26/27 bias of edges 1/2 */
+    uint32_t box;           /* bits 0..4 first column in the tile, 5..10 first row, 11..15 width - 1, 16..21 height - 1 (a tile has up to 40 rows), 26/27 bias of edges 1/2 */
 
     __device__ __forceinline__ void init(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int w, int h)
     {
@@ -801,7 +801,7 @@ struct WalkSetup {
         sx0 = -(es.dy0 << 8); sx1 = -(es.dy1 << 8); sx2 = -(es.dy2 << 8);
         sy0 = es.dx0 << 8; sy1 = es.dx1 << 8; sy2 = es.dx2 << 8;
         z0 = es.z0; gz1 = es.gz1; gz2 = es.gz2; pay_lo = es.pay_lo; pay_hi = es.pay_hi;
-        box = (uint32_t)(x0 - tc.px0) | ((uint32_t)(y0 - tc.py0) << 5) | ((uint32_t)(w - 1) << 10) | ((uint32_t)(h - 1) << 15) |
+        box = (uint32_t)(x0 - tc.px0) | ((uint32_t)(y0 - tc.py0) << 5) | ((uint32_t)(w - 1) << 11) | ((uint32_t)(h - 1) << 16) |
               ((uint32_t)es.bias1 << 26) | ((uint32_t)es.bias2 << 27);
     }
 
@@ -817,14 +817,14 @@ struct WalkSetup {
         return u;
     }
 
-    __device__ __forceinline__ int steps() const { return walk_steps((int)((box >> 10) & 31u) + 1, (int)((box >> 15) & 31u) + 1); }
+    __device__ __forceinline__ int steps() const { return walk_steps((int)((box >> 11) & 31u) + 1, (int)((box >> 16) & 63u) + 1); }
 
     /* steps k0 .. k1-1 of the box: step k is column k % width of strip k / width */
     __device__ __forceinline__ void walk(const TileCtx& tc, int k0, int k1) const
     {
-        const int ow = (int)((box >> 10) & 31u) + 1, oh = (int)((box >> 15) & 31u) + 1;
+        const int ow = (int)((box >> 11) & 31u) + 1, oh = (int)((box >> 16) & 63u) + 1;
         const int32_t b1 = (int32_t)((box >> 26) & 1u), b2 = (int32_t)((box >> 27) & 1u);
-        /* strip and column of step k0 (k0 < 512, ow <= 32): the float quotient by the hardware's reciprocal
+        /* strip and column of step k0 (k0 < 640, ow <= 32): the float quotient by the hardware's reciprocal
          * estimate, whose error is far below one, put right by the remainder */
         int strip = (int)((float)k0 * __builtin_amdgcn_rcpf((float)ow));
         int col = k0 - strip * ow;
@@ -835,7 +835,7 @@ struct WalkSetup {
         int32_t a2 = e2 + __mul24(col, sx2) + __mul24(row, sy2);
         /* from the last column of a strip to the first of the next: two down, ow - 1 back */
         const int32_t nl0 = WALK_ROWS * sy0 - __mul24(ow - 1, sx0), nl1 = WALK_ROWS * sy1 - __mul24(ow - 1, sx1), nl2 = WALK_ROWS * sy2 - __mul24(ow - 1, sx2);
-        uint32_t pix8 = ((((box >> 5) & 31u) + (uint32_t)row) * TILE_W + (box & 31u) + (uint32_t)col) * 8u; /* byte offset of the pixel's word */
+        uint32_t pix8 = ((((box >> 5) & 63u) + (uint32_t)row) * TILE_W + (box & 31u) + (uint32_t)col) * 8u; /* byte offset of the pixel's word */
         /* a box of odd height has no second row in its last strip, whose steps are those from `single` on */
         const int single = (oh & 1) ? __mul24(ow, oh >> 1) : 0x7fffffff;
         EdgeSetup<int32_t, 1> es; /* only its depth plane is used */
@@ -1869,9 +1869,10 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
 #ifndef TILE_WAVES
 #define TILE_WAVES 5 /* waves per SIMD the single-sample kernel is compiled for (96 VGPRs): the walk wants about 110, and below 5 the spills cost more than the occupancy gains */
 #endif
-template <int S>
-__global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_tile(FrameParams fp, uint32_t magic)
+template <int S, int TH>
+__global__ __launch_bounds__(TILE_THREADS, (S == 1 && TH == TILE_H ? TILE_WAVES : 4)) void k_tile(FrameParams fp, uint32_t magic) /* 40 rows of sample words leave LDS for four workgroups per CU */
 {
+    constexpr int TILE_PIXELS = TILE_W * TH; /* TH: rows of pixels per tile (FrameParams::tile_h) */
     __shared__ unsigned long long keys[TILE_PIXELS * S];
     __shared__ ShadeTables tb;
     __shared__ LevelRec pass_levels[16]; /* the levels of the pass-wide texture, indexable per lane */
@@ -1890,9 +1891,9 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
     }
     const int tx = (int)utx, ty = (int)uty;
     TileCtx tc;
-    tc.px0 = tx * TILE_W; tc.py0 = ty * TILE_H;
+    tc.px0 = tx * TILE_W; tc.py0 = ty * TH;
     tc.rx0 = max(tc.px0, fp.clamp_x0); tc.ry0 = max(tc.py0, fp.clamp_y0);
-    tc.rx1 = min(tc.px0 + TILE_W - 1, fp.clamp_x1); tc.ry1 = min(tc.py0 + TILE_H - 1, fp.clamp_y1);
+    tc.rx1 = min(tc.px0 + TILE_W - 1, fp.clamp_x1); tc.ry1 = min(tc.py0 + TH - 1, fp.clamp_y1);
     tc.keys = keys;
     tc.wave_row = wave_rows + (threadIdx.x & ~63u);
     RND_STAMP_START(stamp);
@@ -1948,8 +1949,9 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 ? TILE_WAVES : 4)) void k_til
         const uint32_t ovf = fp.counters[CTR_OVERFLOW];
         /* a list overflowed: the host reports it at the next wait.  The flags go out with their complement beside them: the
          * host takes the pair for a report only when the two agree, so nothing else that might land in that pinned word
-         * reads as one */
-        if (ovf) { fp.status_host[0] = ovf; fp.status_host[1] = ~ovf; }
+         * reads as one.  One aligned 64-bit store: the host, which may look while another frame in flight reports, never
+         * sees the flags of one report beside the complement of none */
+        if (ovf) *reinterpret_cast<volatile unsigned long long*>(fp.status_host) = ((unsigned long long)~ovf << 32) | ovf;
     }
     __syncthreads();
     /* every thread has read the list length: leave the counter clean for the next frame's binning */
@@ -2082,8 +2084,9 @@ void launch_tile(const FrameParams& fp, hipStream_t s, uint32_t lds_pad)
     if (fp.shard_count == 1 && (!fp.grid_w || !fp.grid_h)) return; /* empty render area */
     const uint32_t grid = fp.shard_count == 1 ? rows_of_eight_grid(fp.grid_w, fp.grid_h) : mine;
     const uint32_t magic = rows_of_eight_magic(fp.shard_count == 1 ? fp.grid_w : fp.tiles_x);
-    if (fp.samples == 4) hipLaunchKernelGGL(k_tile<4>, dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
-    else hipLaunchKernelGGL(k_tile<1>, dim3(grid), dim3(TILE_THREADS), (size_t)lds_pad, s, fp, magic);
+    if (fp.samples == 4) hipLaunchKernelGGL((k_tile<4, TILE_H>), dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
+    else if (fp.tile_h == (uint32_t)TILE_H_TALL) hipLaunchKernelGGL((k_tile<1, TILE_H_TALL>), dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
+    else hipLaunchKernelGGL((k_tile<1, TILE_H>), dim3(grid), dim3(TILE_THREADS), (size_t)lds_pad, s, fp, magic);
 }
 
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
