@@ -1308,12 +1308,13 @@ __device__ __forceinline__ void bilinear(const ShadeTables& tb, uint32_t table, 
 
 /* texture() with implicit derivatives: lod = log2(longest footprint axis), clamped to
  * [0, levels-1], trilinear (sampler of tools.cpp:60-82) */
-template <bool PASS_TEX>
+template <bool PASS_TEX, bool CLAMP_LINEAR = false>
 __device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexDesc& desc, LdsLevels lds_levels, float u, float v,
                                                float dudx, float dvdx, float dudy, float dvdy, float* rgb)
 {
     TexView t = view_of(desc);
     if constexpr (PASS_TEX) t.table = 0u; /* the tile kernel stages the pass texture's table first */
+    if constexpr (CLAMP_LINEAR) { t.linear = true; t.tiled = false; } /* the caller has checked the sampler: LINEAR, CLAMP_TO_EDGE (tools.cpp:60-82) */
     const float w0 = (float)t.width, h0 = (float)t.height;
     const float mxu = dudx * w0, mxv = dvdx * h0, myu = dudy * w0, myv = dvdy * h0;
     const float rx = fma32(mxv, mxv, mxu * mxu), ry = fma32(myv, myv, myu * myu);
@@ -1502,11 +1503,14 @@ __device__ __forceinline__ void to_parent(const float* bary, float* q)
 /* The fragment shader proper: everything after the corners' data are in registers.  c: window positions and
  * 1/w of the triangle the weights are taken over (a fan triangle when clipped); v0..v2: the vertex shader's
  * outputs at the PARENT's corners; bary (clipped only): the fan triangle's corners as weights over the parent's. */
+template <bool SPEC>
 __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels, uint32_t draw,
                                                int shader, int texture, const Corners& c, const Varyings& v0, const Varyings& v1,
                                                const Varyings& v2, const float* bary, int x, int y, float* rgba)
 {
-    const bool want_derivs = texture >= 0;
+    /* SPEC: every draw of the pass runs the dummy or the test_ktx shader on one texture sampled LINEAR with CLAMP_TO_EDGE
+     * (what the reference's samples record): shader and texture are the pass's, nothing about them is asked per lane */
+    const bool want_derivs = SPEC || texture >= 0;
     /* weights over the parent's corners at the pixel centre, and at the neighbour in x and the
      * neighbour in y of the 2x2 quad (same primitive, extrapolated) for the derivatives */
     float lam[3], lnx[3], lny[3]; /* lnx, lny: written and read only where derivatives are wanted */
@@ -1517,8 +1521,8 @@ __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Shad
     }
 
     float tex[3] = {1.0f, 1.0f, 1.0f};
-    if (shader == 0 || shader == 1) {
-        if (texture >= 0) {
+    if (SPEC || shader == 0 || shader == 1) {
+        if (SPEC || texture >= 0) {
             float u = interp(lam, v0.uv[0], v1.uv[0], v2.uv[0]), v = interp(lam, v0.uv[1], v1.uv[1], v2.uv[1]);
             float unx = interp(lnx, v0.uv[0], v1.uv[0], v2.uv[0]), vnx = interp(lnx, v0.uv[1], v1.uv[1], v2.uv[1]);
             float uny = interp(lny, v0.uv[0], v1.uv[0], v2.uv[0]), vny = interp(lny, v0.uv[1], v1.uv[1], v2.uv[1]);
@@ -1526,7 +1530,8 @@ __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Shad
             /* toward the quad neighbour, which lies on either side: the sampler squares these, so the direction
              * does not reach the result (a difference and its negative have the same square) */
             const float dudx = unx - u, dvdx = vnx - v, dudy = uny - u, dvdy = vny - v;
-            if (fp.pass_texture >= 0) sample_texture<true>(tb, fp.pass_tex, pass_levels, u, v, dudx, dvdx, dudy, dvdy, tex);
+            if constexpr (SPEC) sample_texture<true, true>(tb, fp.pass_tex, pass_levels, u, v, dudx, dvdx, dudy, dvdy, tex);
+            else if (fp.pass_texture >= 0) sample_texture<true>(tb, fp.pass_tex, pass_levels, u, v, dudx, dvdx, dudy, dvdy, tex);
             else sample_texture<false>(tb, fp.textures[texture], nullptr, u, v, dudx, dvdx, dudy, dvdy, tex);
         } else {
             tex[0] = tex[1] = tex[2] = 0.0f;
@@ -1534,7 +1539,7 @@ __device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Shad
     }
     if (shader == 0) { rgba[0] = tex[0]; rgba[1] = tex[1]; rgba[2] = tex[2]; rgba[3] = 1.0f; return; }
     const float diff = fmaxf(interp(lam, v0.light, v1.light, v2.light), 0.0f);
-    if (shader == 1) {
+    if (SPEC || shader == 1) {
         rgba[0] = tex[0] * diff; rgba[1] = tex[1] * diff; rgba[2] = tex[2] * diff;
     } else {
         /* v_color = push colour at every corner, interpolated like any other varying */
@@ -1556,6 +1561,7 @@ __device__ __forceinline__ void shader_and_texture(const FrameParams& fp, uint32
 }
 
 /* colour of the fragment of (slot, sub) at pixel (x, y), everything gathered from device memory */
+template <bool SPEC>
 __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
                             uint32_t slot, uint32_t sub, bool clipped, int x, int y, float* rgba)
 {
@@ -1577,7 +1583,8 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
         vtx[0] = ct->v[0]; vtx[1] = ct->v[1]; vtx[2] = ct->v[2];
     }
     int shader, texture;
-    shader_and_texture(fp, draw, shader, texture);
+    if constexpr (SPEC) { shader = fp.pass_shader; texture = fp.pass_texture; }
+    else shader_and_texture(fp, draw, shader, texture);
     Varyings v0, v1, v2;
     load_varyings(fp, vtx[0], v0);
     load_varyings(fp, vtx[1], v1);
@@ -1599,7 +1606,7 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
         for (int k = 0; k < 3; ++k) { c.x[k] = ct->x[k]; c.y[k] = ct->y[k]; c.iw[k] = ct->iw[k]; }
         bary = ct->bary;
     }
-    shade_fragment(fp, tb, pass_levels, draw, shader, texture, c, v0, v1, v2, bary, x, y, rgba);
+    shade_fragment<SPEC>(fp, tb, pass_levels, draw, shader, texture, c, v0, v1, v2, bary, x, y, rgba);
 }
 
 __device__ __forceinline__ uint32_t pack_color(const FrameParams& fp, const ShadeTables& tb, const float* rgba)
@@ -1802,7 +1809,7 @@ constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* owner word of a sample no fragment
 
 /* Colour of pixel (x, y), whose samples are owned by vis[0..S): shade each distinct owner once,
  * resolve, encode, store. */
-template <int S>
+template <int S, bool SPEC>
 __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
                                                 int x, int y, uint32_t pi, const uint32_t* vis)
 {
@@ -1816,7 +1823,7 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
         if (RND_PROBE(fp, 1u)) {
             smp[0][0] = smp[0][1] = smp[0][2] = smp[0][3] = 0.5f;
         } else {
-            shade_pixel(fp, tb, pass_levels, vis[0] & SLOT_MASK, (vis[0] >> ENTRY_SUB_SHIFT) & 7u, (vis[0] & FLAG_CLIPPED) != 0u, x, y, smp[0]);
+            shade_pixel<SPEC>(fp, tb, pass_levels, vis[0] & SLOT_MASK, (vis[0] >> ENTRY_SUB_SHIFT) & 7u, (vis[0] & FLAG_CLIPPED) != 0u, x, y, smp[0]);
         }
     } else {
         /* Several samples: one shading per distinct owner, as a loop with ONE copy of the shading code.  Each
@@ -1840,7 +1847,7 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
 #pragma unroll
             for (int s = S - 1; s >= 0; --s) if (todo & (1u << s)) owner = vis[s]; /* the first sample still to do */
             float c[4];
-            shade_pixel(fp, tb, pass_levels, owner & SLOT_MASK, (owner >> ENTRY_SUB_SHIFT) & 7u, (owner & FLAG_CLIPPED) != 0u, x, y, c);
+            shade_pixel<SPEC>(fp, tb, pass_levels, owner & SLOT_MASK, (owner >> ENTRY_SUB_SHIFT) & 7u, (owner & FLAG_CLIPPED) != 0u, x, y, c);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 if ((todo & (1u << s)) && vis[s] == owner) {
@@ -1869,7 +1876,7 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
 #ifndef TILE_WAVES
 #define TILE_WAVES 5 /* waves per SIMD the single-sample kernel is compiled for (96 VGPRs): the walk wants about 110, and below 5 the spills cost more than the occupancy gains */
 #endif
-template <int S, int TH>
+template <int S, int TH, bool SPEC>
 __global__ __launch_bounds__(TILE_THREADS, (S == 1 && TH == TILE_H ? TILE_WAVES : 4)) void k_tile(FrameParams fp, uint32_t magic) /* 40 rows of sample words leave LDS for four workgroups per CU */
 {
     constexpr int TILE_PIXELS = TILE_W * TH; /* TH: rows of pixels per tile (FrameParams::tile_h) */
@@ -1974,7 +1981,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 && TH == TILE_H ? TILE_WAVES 
                 vis[s] = ((fp.depth_less ? low : ~low) & SLOT_MASK) | (fan_clipped << ENTRY_SUB_SHIFT);
             }
         }
-        shade_and_store<S>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);
+        shade_and_store<S, SPEC>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);
     }
     RND_STAMP(fp, stamp, 8); /* shading */
     RND_STAMP_END(fp);
@@ -2076,6 +2083,13 @@ void launch_setup(const FrameParams& fp, hipStream_t s)
     hipLaunchKernelGGL(k_setup, dim3(blocks), dim3(256), 0, s, fp);
 }
 
+/* RND_TILE_GENERIC=1: every pass takes the general instantiation of the tile kernel (for A/B runs and the tests) */
+static bool getenv_no_spec()
+{
+    static const bool v = [] { const char* e = getenv("RND_TILE_GENERIC"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 void launch_tile(const FrameParams& fp, hipStream_t s, uint32_t lds_pad)
 {
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
@@ -2084,9 +2098,20 @@ void launch_tile(const FrameParams& fp, hipStream_t s, uint32_t lds_pad)
     if (fp.shard_count == 1 && (!fp.grid_w || !fp.grid_h)) return; /* empty render area */
     const uint32_t grid = fp.shard_count == 1 ? rows_of_eight_grid(fp.grid_w, fp.grid_h) : mine;
     const uint32_t magic = rows_of_eight_magic(fp.shard_count == 1 ? fp.grid_w : fp.tiles_x);
-    if (fp.samples == 4) hipLaunchKernelGGL((k_tile<4, TILE_H>), dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
-    else if (fp.tile_h == (uint32_t)TILE_H_TALL) hipLaunchKernelGGL((k_tile<1, TILE_H_TALL>), dim3(grid), dim3(TILE_THREADS), 0, s, fp, magic);
-    else hipLaunchKernelGGL((k_tile<1, TILE_H>), dim3(grid), dim3(TILE_THREADS), (size_t)lds_pad, s, fp, magic);
+    /* the instantiation for passes of the samples' kind: one texture for every draw, sampled LINEAR with CLAMP_TO_EDGE, by the
+     * dummy or the test_ktx shader */
+    const bool spec = !getenv_no_spec() && fp.pass_texture >= 0 && (fp.pass_shader == 0 || fp.pass_shader == 1) && fp.pass_tex.filter_linear != 0u && fp.pass_tex.tiled == 0u;
+    const dim3 g(grid), b(TILE_THREADS);
+    if (fp.samples == 4) {
+        if (spec) hipLaunchKernelGGL((k_tile<4, TILE_H, true>), g, b, 0, s, fp, magic);
+        else hipLaunchKernelGGL((k_tile<4, TILE_H, false>), g, b, 0, s, fp, magic);
+    } else if (fp.tile_h == (uint32_t)TILE_H_TALL) {
+        if (spec) hipLaunchKernelGGL((k_tile<1, TILE_H_TALL, true>), g, b, 0, s, fp, magic);
+        else hipLaunchKernelGGL((k_tile<1, TILE_H_TALL, false>), g, b, 0, s, fp, magic);
+    } else {
+        if (spec) hipLaunchKernelGGL((k_tile<1, TILE_H, true>), g, b, (size_t)lds_pad, s, fp, magic);
+        else hipLaunchKernelGGL((k_tile<1, TILE_H, false>), g, b, (size_t)lds_pad, s, fp, magic);
+    }
 }
 
 void launch_mip(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, int srgb,
