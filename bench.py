@@ -197,17 +197,45 @@ def measured_copy_peak(dev, reps=8):
         tgt.destroy()
 
 
-def measured_counters(kernel, config):
-    """The committed counter pass of this workload for `kernel` (profiles/traffic.json, written by
-    tools/summarize_profiles.py from rocprofv3 --pmc runs of this same command): HBM bytes per
-    launch (FETCH_SIZE / WRITE_SIZE) and vector-ALU instructions per launch (SQ_INSTS_VALU).
-    (None, None) when there is no pass for this workload."""
+KERNEL_SOURCES = ("rnd_kernels.hip", "rnd_device.h", "rnd_internal.h")
+
+
+def kernel_source_id():
+    """First 16 hex digits of the SHA-256 over the kernels' source files as they are in this tree: what a counter pass
+    belongs to (the counters change when the kernels do, not when host code does)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "renderer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def counter_table(config):
+    """The committed counter pass of this workload (profiles/traffic.json, written by tools/summarize_profiles.py from
+    rocprofv3 --pmc runs of this same command) and where it came from: ({kernel: row}, {"tag", "kernel_source_id",
+    "matches_this_tree"}).  The table is empty when the pass was collected on other kernel sources than this tree's:
+    its numbers then describe another build and the line says null instead."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            table = json.load(f).get("config%d" % config, {})
+            whole = json.load(f)
     except (OSError, ValueError):
-        return None, None
+        return {}, None
+    table = whole.get("config%d" % config, {})
+    origin = whole.get("collected", {}).get("config%d" % config)
+    if not table:
+        return {}, origin
+    if origin is None:
+        return {}, {"tag": None, "kernel_source_id": None, "matches_this_tree": False}
+    origin = dict(origin, matches_this_tree=origin.get("kernel_source_id") == kernel_source_id())
+    return (table if origin["matches_this_tree"] else {}), origin
+
+
+def measured_counters(kernel, config):
+    """HBM bytes per launch (size-resolved read requests + WRITE_SIZE) and vector-ALU instructions per launch
+    (SQ_INSTS_VALU) of `kernel` from the committed counter pass; (None, None) when there is none for this build."""
+    table, _ = counter_table(config)
     for name, row in table.items():
         if name.split("<")[0] == kernel:
             return int(row["read_bytes"] + row["write_bytes"]), row.get("valu_insts")
@@ -217,11 +245,7 @@ def measured_counters(kernel, config):
 def measured_frame_totals(config):
     """Vector-ALU instructions and L2<->HBM bytes of one frame's kernels together, from the same committed counter pass
     ((None, None) without one)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            table = json.load(f).get("config%d" % config, {})
-    except (OSError, ValueError):
-        return None, None
+    table, _ = counter_table(config)
     rows = [row for name, row in table.items() if name.split("<")[0] in FRAME_KERNELS]
     valu = sum(row.get("valu_insts") or 0 for row in rows)
     traffic = sum((row.get("read_bytes") or 0) + (row.get("write_bytes") or 0) for row in rows)
@@ -459,7 +483,7 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
     # per-kernel durations, HIP events on the library's own stream
     roofline = None
     stages = {}
-    if rank == 0 and profile:
+    if rank == 0 and profile and args.profile_steps > 0:
         run.dev.set_profiling(True)
         acc = {}
         for i in range(args.profile_steps):
@@ -477,6 +501,8 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
         share = scene.algorithmic_bytes_by_stage()[dom]
         if tiles_mode:
             share = share / world
+        elif args.one_shard_of > 1:
+            share = share / args.one_shard_of  # a rehearsal renders one rank's share of the frame
         achieved = share / (stages[dom] * 1e-3) / 1e9
         traffic, valu = measured_counters("k_" + dom, config) if args.samples == 1 and not tiles_mode and args.one_shard_of == 1 else (None, None)  # counter passes are whole frames at one sample
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -539,6 +565,9 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
             "gather_ms": None if gather_ms is None else round(gather_ms, 5),
             "render_ms": None if gather_ms is None else round(elapsed / steps * 1e3 - gather_ms, 5),
             "roofline": roofline, "cpu_baseline": cpu_line,
+            # where roofline.traffic / valu_busy / frame_valu_busy / frame_traffic_* come from: the tag of the committed
+            # rocprofv3 counter pass and the kernel sources it was collected on; they are null when this tree's differ
+            "counters_from": counter_table(config)[1] if whole_frames else None,
         }
     run.destroy()
     return out

@@ -489,3 +489,90 @@ def test_srgb_encode_against_the_printed_formula(oracle):
     assert skipped < 40
     table = [lib.orc_srgb_decode(k) for k in range(256)]
     assert np.abs(np.array(table) - srgb_to_linear(np.arange(256) / 255.0)).max() < 1e-7
+
+
+# ------------------------------------------------------------------ depth words against the plane through the snapped corners
+
+def _f32(x):
+    return np.float32(x)
+
+
+def _fma32(a, b, c):
+    """float32 fused multiply-add: the product of two float32 is exact in float64, the sum is then rounded twice (to
+    float64, to float32), which differs from the fused result only when the float64 sum lies within 2^-29 of a float32 tie."""
+    return np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+
+
+def snapped_corners_and_depths(sc):
+    """Per triangle of a one-draw scene whose uniform block holds the matrix alone (window_soup): the three corners'
+    window positions in 1/256 pixel after the snap and their window depths, computed in float32 the way the pinned
+    vertex stage says (M * (pos, 1) as three multiply-adds from the last column on, y = 1 - y, 1 / w, the viewport
+    transform as one multiply-add per axis, floor(v * 256 + 1/2)); None for a triangle with a corner outside the guard band of 2 w."""
+    dr = sc.draws[0]
+    m = np.asarray(sc.ubos[dr["ubo"]], dtype=np.float32)[64:80]  # column-major mvp; the push transform is the identity
+    vb = np.asarray(sc.vbs[dr["vb"]], dtype=np.float32).reshape(-1, 8)
+    ib = np.asarray(sc.ibs[dr["ib"]]).reshape(-1)[dr.get("first_index", 0):][:dr["index_count"]]
+    vx, vy, vw, vh, zmin, zmax = [np.float32(t) for t in sc.viewport]
+    half_w, half_h = vw * _f32(0.5), vh * _f32(0.5)
+    ox, oy, pz = vx + half_w, vy + half_h, zmax - zmin
+    out = []
+    for t in range(len(ib) // 3):
+        tri = []
+        for v in vb[ib[3 * t:3 * t + 3]]:
+            x, y, z = v[0], v[1], v[2]
+            clip = []
+            for row in range(4):
+                acc = _fma32(m[2 * 4 + row], z, m[3 * 4 + row])
+                acc = _fma32(m[1 * 4 + row], y, acc)
+                acc = _fma32(m[0 * 4 + row], x, acc)
+                clip.append(acc)
+            cx, cy, cz, cw = clip[0], _f32(1.0) - clip[1], clip[2], clip[3]
+            if not (cw > 0 and abs(cx) <= 2 * cw and abs(cy) <= 2 * cw and 0 <= cz <= cw):
+                tri = None
+                break
+            iw = _f32(1.0) / cw
+            xw, yw = _fma32(cx * iw, half_w, ox), _fma32(cy * iw, half_h, oy)
+            xs, ys = math.floor(float(_fma32(xw, _f32(256.0), _f32(0.5)))), math.floor(float(_fma32(yw, _f32(256.0), _f32(0.5))))
+            tri.append((xs, ys, float(_fma32(cz * iw, pz, zmin))))
+        out.append(tri)
+    return out
+
+
+def test_depth_words_against_the_plane_through_the_snapped_corners(oracle):
+    """Sloped triangles with a w per corner.  The depth of a fragment is the value at the pixel centre of the plane through
+    the three SNAPPED corners (window depth is affine in window space); in float64 that value has no error to speak of, so
+    round-to-nearest of it times 2^24 - 1 is what an ideal rasteriser stores.  The oracle interpolates in float32 (depth at
+    corner 0 plus two multiply-adds of edge values by gradients): its words are compared with the ideal ones exactly --
+    no allowance for the snap, which both sides apply -- and the test reports how many are equal, how many one step off and
+    how many more; it fails beyond two steps (float32 carries 24 bits, a D24 step above depth 1/2 is one unit in its last place)."""
+    equal = one = two = more = 0
+    worst = 0
+    for seed in range(30):
+        sc = window_soup(48, 40, 8, 100 + seed, textured=False)
+        attach_levels(sc, oracle)
+        _, depth, prim = oracle.render_scene(sc, want_prim=True)
+        fr, _, _ = render64(sc)
+        sure = ~fr.unsure & (fr.owner >= 0)
+        owner = prim[..., 0].astype(np.int64)
+        py, px = np.mgrid[0:sc.height, 0:sc.width]
+        for t, tri in enumerate(snapped_corners_and_depths(sc)):
+            mask = sure & (fr.owner == t) & (owner == t)
+            if tri is None or not mask.any():
+                continue
+            (x0, y0, z0), (x1, y1, z1), (x2, y2, z2) = [(a / 256.0, b / 256.0, c) for a, b, c in tri]
+            det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0)
+            if det == 0:
+                continue
+            gx = ((z1 - z0) * (y2 - y0) - (z2 - z0) * (y1 - y0)) / det
+            gy = ((z2 - z0) * (x1 - x0) - (z1 - z0) * (x2 - x0)) / det
+            z = z0 + gx * (px[mask] + 0.5 - x0) + gy * (py[mask] + 0.5 - y0)
+            ideal = np.floor(np.clip(z, 0.0, 1.0) * D24_MAX + 0.5).astype(np.int64)
+            d = np.abs(depth[..., 0][mask].astype(np.int64) - ideal)
+            equal += int((d == 0).sum()); one += int((d == 1).sum()); two += int((d == 2).sum()); more += int((d > 2).sum())
+            worst = max(worst, int(d.max()))
+    total = equal + one + two + more
+    report = "of %d depth words: %.1f %% equal the ideal word, %.1f %% are one step off, %.2f %% two, %d more (worst %d)" % (
+        total, 100.0 * equal / total, 100.0 * one / total, 100.0 * two / total, more, worst)
+    print(report)
+    assert total > 8000, report
+    assert more == 0 and equal >= 0.5 * total and equal + one >= 0.97 * total, report

@@ -80,6 +80,10 @@ def main(src, dst_prefix, config=None):
         except (OSError, ValueError):
             table = {}
         table["config%d" % config] = {k: v for k, v in traffic.items() if k.startswith("k_")}
+        # which build the pass belongs to: bench.py reports the counters only for the same kernel sources
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        table.setdefault("collected", {})["config%d" % config] = {"tag": os.path.basename(dst_prefix), "kernel_source_id": bench.kernel_source_id()}
         with open(path, "w") as f:
             json.dump(table, f, indent=1, sort_keys=True)
         print("updated", path)
