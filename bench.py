@@ -19,12 +19,14 @@ N > 1 runs one rank per GPU.  Launched by torch.distributed.run (WORLD_SIZE set)
 rank; launched plainly with --gpus N it starts the N ranks itself as a child process, before
 anything touches a GPU, and relays rank 0's line.  The N-GPU line carries three measurements:
   value / ms_per_step   every rank renders its own view of configs[1] (independent views, no
-                        collective on the data path: weak scaling);
-  "bands_8k"            configs[3]: ONE 7680x4320 frame divided into bands of rows of tiles, one per
-                        rank (each rank's render area; the library skips the draws outside it), the
+                        collective on the data path: weak scaling) -- the same workload as the one-GPU
+                        line, so that `value` compares across N;
+  "strong_scaling"      configs[3]: ONE 7680x4320 frame divided into bands of rows of tiles, one per
+   (= "bands_8k")       rank (each rank's render area; the library skips the draws outside it), the
                         finished bands exchanged by one RCCL all_gather overlapped with the next
-                        frame's rendering (strong scaling; render and exchange times apart, and the
-                        gathered frame checked against the unsharded one);
+                        frame's rendering (render and exchange times apart, the gathered frame checked
+                        against the unsharded one), beside the same frame rendered whole by rank 0
+                        alone in the same run: speedup and efficiency = speedup / N are in the line;
   "multiview_10m"       configs[4]: the 64 cameras of the orbit over the 10 M-triangle scene dealt
                         to the ranks (64 / N views each), no exchange.
 --mode tiles | bands with --config C runs that one sharded mode alone, as before.
@@ -538,7 +540,8 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
             mode, world, ", exchange of a frame overlapped with the next frame's rendering" if pipelined else "")) if tiles_mode
             else ("rehearsal: the %s of rank %d of %d only" % (mode if bands else "tiles", args.shard_rank, args.one_shard_of)) if args.one_shard_of > 1
             else ("the %d views of the orbit dealt to %d GPU%s, no exchange" % (N_VIEWS, world, "" if world == 1 else "s")) if multiview
-            else ("one view per GPU, %d GPUs" % world))
+            else ("one view per GPU, %d GPU%s%s" % (world, "" if world == 1 else "s", "" if world == 1 else
+                  " (weak scaling: every GPU renders the one-GPU line's workload; one frame divided among the GPUs is under strong_scaling)")))
         out = {
             "metric": "shaded_mpix_per_s", "value": round(mpix, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -575,7 +578,8 @@ def bench_once(args, ctx, config, mode, steps, warmup, profile=True, cpu=False, 
 
 def brief(line):
     """What the N-GPU line keeps of a secondary measurement."""
-    keys = ("value", "unit", "mtri_per_s", "ms_per_step", "steps", "scaling", "tiles_check", "gather_ms", "render_ms", "frame_hbm_frac")
+    keys = ("value", "unit", "mtri_per_s", "ms_per_step", "steps", "scaling", "tiles_check", "gather_ms", "render_ms", "frame_hbm_frac",
+            "one_gpu_ms_per_frame", "speedup_vs_one_gpu", "efficiency")
     out = {k: line[k] for k in keys if line.get(k) is not None}
     out["workload"] = line["config"]["workload"]
     out["sharding"] = line["config"]["sharding"]
@@ -644,7 +648,24 @@ def main():
         extra = copy.copy(args)
         extra.repeats = 0
         # a leg that fails says so in its place: the line's own measurement above is already taken
-        legs = (("bands_8k", lambda: bench_once(extra, ctx, 3, "bands", max(10, min(args.steps, 40)), max(2, min(args.warmup, 5)), profile=False)),
+        def bands_with_baseline():
+            """The 8K frame in bands over all ranks, then the same frame whole on rank 0 alone (the other ranks wait at
+            the barrier that follows): what dividing one frame among N GPUs gains over one GPU, from one run."""
+            line = bench_once(extra, ctx, 3, "bands", max(10, min(args.steps, 40)), max(2, min(args.warmup, 5)), profile=False)
+            solo = None
+            if rank == 0:
+                alone = dict(ctx, world=1, dist=None)
+                one = copy.copy(extra)
+                one.frames_in_flight = 2  # as the bands leg: one frame rendered while the previous is exchanged
+                solo = bench_once(one, alone, 3, "views", max(10, min(args.steps, 40)), max(2, min(args.warmup, 5)), profile=False, frames_per_step=1)
+            dist.barrier()
+            if rank == 0:
+                line["one_gpu_ms_per_frame"] = solo["ms_per_frame"]
+                line["speedup_vs_one_gpu"] = round(solo["ms_per_frame"] / line["ms_per_step"], 3)
+                line["efficiency"] = round(solo["ms_per_frame"] / line["ms_per_step"] / world, 3)
+            return line
+
+        legs = (("bands_8k", bands_with_baseline),
                 ("multiview_10m", lambda: bench_once(extra, ctx, 4, "views", 3 * max(1, N_VIEWS // world), max(1, N_VIEWS // world), profile=False)))
         # The line's own measurement is taken.  A leg in which one rank fails and the others wait for it in a collective would
         # keep every rank waiting until the process group's own time limit ends them all without a line: every rank therefore
@@ -669,6 +690,9 @@ def main():
                 line = leg()
                 if rank == 0:
                     out[name] = brief(line)
+                    if name == "bands_8k":
+                        # the strong-scaling figure under a name that says so, at the top level
+                        out["strong_scaling"] = dict(out[name], n_gpus=world)
             except Exception as e:  # noqa: BLE001 - reported, not hidden
                 if rank == 0:
                     out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
