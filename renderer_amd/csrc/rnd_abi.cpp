@@ -588,7 +588,7 @@ int texture_alloc(rnd_device dev, uint32_t w, uint32_t h, int32_t format, uint32
                   rnd_texture* out)
 {
     if (!w || !h || w > 16384 || h > 16384) return fail(RND_ERROR_INVALID_ARGUMENT, "texture extent out of range");
-    if (levels < 1 || levels > 16) return fail(RND_ERROR_INVALID_ARGUMENT, "texture level count out of range");
+    if (levels < 1 || levels > (uint32_t)MAX_TEXTURE_LEVELS) return fail(RND_ERROR_INVALID_ARGUMENT, "texture level count out of range (a side of at most 16384 texels has at most 15 levels)");
     rnd_texture t = new rnd_texture_t();
     t->dev = dev; t->width = w; t->height = h; t->levels = levels; t->srgb = format_is_srgb(format) ? 1u : 0u;
     t->sampler = sampler ? *sampler : rnd_sampler_info{RND_FILTER_LINEAR, 0, 0.0f};

@@ -85,7 +85,8 @@ __device__ __forceinline__ uint32_t depth24(float z)
  * every value has code 0 like 2^-13 itself, from thr[255] (which lies below the largest float under 1) on every value
  * has code 255 like that float; a NaN comes out of the median as the lower bound, code 0.  The three channels of a
  * pixel then run their two table reads side by side instead of one branch after the other. */
-__device__ __forceinline__ uint32_t srgb_encode(const ShadeTables& tb, float c)
+template <typename Tables>
+__device__ __forceinline__ uint32_t srgb_encode(const Tables& tb, float c)
 {
     const float cc = __builtin_amdgcn_fmed3f(c, 1.220703125e-4f, 0.99999994f);
     const uint32_t key = (__float_as_uint(cc) >> SRGB_LUT_SHIFT) - SRGB_LUT_FIRST;

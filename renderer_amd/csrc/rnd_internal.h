@@ -54,6 +54,17 @@ struct __attribute__((aligned(16))) ShadeTables {
     uint8_t pad[12]; /* size is a multiple of 16 bytes */
 };
 
+/* The same without the second texel table: what the tile kernel stages when every texel of the pass decodes through one table
+ * (the pass's texture's, staged as value[0]).  The kilobyte saved is what lets five workgroups of 40-row tiles share a CU. */
+struct __attribute__((aligned(16))) PassTables {
+    float value[1][256];
+    float thr[257];
+    uint8_t lut[SRGB_LUT_SIZE];
+    uint8_t pad[12];
+};
+static_assert(sizeof(PassTables) + 1024 == sizeof(ShadeTables) && sizeof(PassTables) % 16 == 0, "PassTables is ShadeTables less value[1]");
+constexpr int MAX_TEXTURE_LEVELS = 15; /* a side of at most 16384 texels has at most 15 levels */
+
 /* Bits of TileEntry::slot_flags and PrimRec::draw_flags */
 constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   /* primitive slot (submission number) */
 constexpr uint32_t ENTRY_SUB_SHIFT = 28;      /* bits 28..30: fan index of a clipped primitive's triangle */

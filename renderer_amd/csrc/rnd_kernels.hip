@@ -21,6 +21,10 @@
  */
 #include "rnd_device.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
 /* Scratch of rnd_draw_indexed_noalloc: every buffer a frame's kernels hand to one another (screen-space vertices, tile
  * lists, counters, ...), laid out by rnd::NoAllocLayout.  In host code this name is only a handle for
  * hipGetSymbolAddress; kernels get the address that call returns. */
@@ -1191,7 +1195,8 @@ __device__ __forceinline__ uint32_t load_texel(const uint8_t* lv, uint32_t byte_
     return *(GlobalTexel)(lv + byte_offset);
 }
 
-__device__ __forceinline__ void decode_texel(const ShadeTables& tb, uint32_t table, uint32_t p, float* rgb)
+template <typename Tables>
+__device__ __forceinline__ void decode_texel(const Tables& tb, uint32_t table, uint32_t p, float* rgb)
 {
     const float* value = tb.value[table];
     rgb[0] = value[p & 255u]; rgb[1] = value[(p >> 8) & 255u]; rgb[2] = value[(p >> 16) & 255u];
@@ -1291,7 +1296,8 @@ __device__ __forceinline__ uint32_t nearest_tap(const TexView& t, uint32_t level
     return (__umul24((uint32_t)y, (uint32_t)w) + (uint32_t)x) << 2;
 }
 
-__device__ __forceinline__ void bilinear(const ShadeTables& tb, uint32_t table, const uint32_t* p, float ax, float ay, float* rgb)
+template <typename Tables>
+__device__ __forceinline__ void bilinear(const Tables& tb, uint32_t table, const uint32_t* p, float ax, float ay, float* rgb)
 {
     float c00[3], c10[3], c01[3], c11[3];
     decode_texel(tb, table, p[0], c00);
@@ -1308,8 +1314,8 @@ __device__ __forceinline__ void bilinear(const ShadeTables& tb, uint32_t table, 
 
 /* texture() with implicit derivatives: lod = log2(longest footprint axis), clamped to
  * [0, levels-1], trilinear (sampler of tools.cpp:60-82) */
-template <bool PASS_TEX, bool CLAMP_LINEAR = false>
-__device__ __forceinline__ void sample_texture(const ShadeTables& tb, const TexDesc& desc, LdsLevels lds_levels, float u, float v,
+template <bool PASS_TEX, bool CLAMP_LINEAR = false, typename Tables>
+__device__ __forceinline__ void sample_texture(const Tables& tb, const TexDesc& desc, LdsLevels lds_levels, float u, float v,
                                                float dudx, float dvdx, float dudy, float dvdy, float* rgb)
 {
     TexView t = view_of(desc);
@@ -1503,8 +1509,8 @@ __device__ __forceinline__ void to_parent(const float* bary, float* q)
 /* The fragment shader proper: everything after the corners' data are in registers.  c: window positions and
  * 1/w of the triangle the weights are taken over (a fan triangle when clipped); v0..v2: the vertex shader's
  * outputs at the PARENT's corners; bary (clipped only): the fan triangle's corners as weights over the parent's. */
-template <bool SPEC>
-__device__ __forceinline__ void shade_fragment(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels, uint32_t draw,
+template <bool SPEC, typename Tables>
+__device__ __forceinline__ void shade_fragment(const FrameParams& fp, const Tables& tb, LdsLevels pass_levels, uint32_t draw,
                                                int shader, int texture, const Corners& c, const Varyings& v0, const Varyings& v1,
                                                const Varyings& v2, const float* bary, int x, int y, float* rgba)
 {
@@ -1561,8 +1567,8 @@ __device__ __forceinline__ void shader_and_texture(const FrameParams& fp, uint32
 }
 
 /* colour of the fragment of (slot, sub) at pixel (x, y), everything gathered from device memory */
-template <bool SPEC>
-__device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
+template <bool SPEC, typename Tables>
+__device__ void shade_pixel(const FrameParams& fp, const Tables& tb, LdsLevels pass_levels,
                             uint32_t slot, uint32_t sub, bool clipped, int x, int y, float* rgba)
 {
     PrimRec pr;
@@ -1609,7 +1615,8 @@ __device__ void shade_pixel(const FrameParams& fp, const ShadeTables& tb, LdsLev
     shade_fragment<SPEC>(fp, tb, pass_levels, draw, shader, texture, c, v0, v1, v2, bary, x, y, rgba);
 }
 
-__device__ __forceinline__ uint32_t pack_color(const FrameParams& fp, const ShadeTables& tb, const float* rgba)
+template <typename Tables>
+__device__ __forceinline__ uint32_t pack_color(const FrameParams& fp, const Tables& tb, const float* rgba)
 {
     uint32_t r, g, b;
     if (fp.color_srgb) { r = srgb_encode(tb, rgba[0]); g = srgb_encode(tb, rgba[1]); b = srgb_encode(tb, rgba[2]); }
@@ -1797,6 +1804,21 @@ __device__ __forceinline__ void stage_tables(ShadeTables& tb, const ShadeTables*
     }
 }
 
+/* the same for the tables of a pass whose texels all decode through table `which`: that table as value[0], then the
+ * encoder's thresholds and buckets, which lie one table further on in the source */
+__device__ __forceinline__ void stage_tables(PassTables& tb, const ShadeTables* src, bool second_table)
+{
+    constexpr uint32_t PIECES = sizeof(PassTables) / 16;
+    const uint32_t lds_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(&tb));
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    const uint8_t* g = reinterpret_cast<const uint8_t*>(src);
+    for (uint32_t first = wave_first; first < PIECES; first += blockDim.x) {
+        const uint32_t i = first + (threadIdx.x & 63u);
+        const uint32_t from = i < 64u ? (second_table ? i + 64u : i) : i + 64u;
+        if (i < PIECES) async_copy16(g + (size_t)from * 16u, lds_first + first * 16u);
+    }
+}
+
 /* one word into an image at a 32-bit byte offset: the store takes the image's address as its scalar base and the offset
  * as it is, where an index into a 64-bit pointer costs a 64-bit multiply-add per pixel */
 __device__ __forceinline__ void store_word(void* image, uint32_t byte_offset, uint32_t value)
@@ -1809,8 +1831,8 @@ constexpr uint32_t VIS_NONE = 0xFFFFFFFFu; /* owner word of a sample no fragment
 
 /* Colour of pixel (x, y), whose samples are owned by vis[0..S): shade each distinct owner once,
  * resolve, encode, store. */
-template <int S, bool SPEC>
-__device__ __forceinline__ void shade_and_store(const FrameParams& fp, const ShadeTables& tb, LdsLevels pass_levels,
+template <int S, bool SPEC, typename Tables>
+__device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Tables& tb, LdsLevels pass_levels,
                                                 int x, int y, uint32_t pi, const uint32_t* vis)
 {
     /* no fragment landed on the pixel: the clear colour, encoded once on the host */
@@ -1877,12 +1899,12 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Sha
 #define TILE_WAVES 5 /* waves per SIMD the single-sample kernel is compiled for (96 VGPRs): the walk wants about 110, and below 5 the spills cost more than the occupancy gains */
 #endif
 template <int S, int TH, bool SPEC>
-__global__ __launch_bounds__(TILE_THREADS, (S == 1 && TH == TILE_H ? TILE_WAVES : 4)) void k_tile(FrameParams fp, uint32_t magic) /* 40 rows of sample words leave LDS for four workgroups per CU */
+__global__ __launch_bounds__(TILE_THREADS, (S == 1 && (TH == TILE_H || SPEC) ? TILE_WAVES : 4)) void k_tile(FrameParams fp, uint32_t magic) /* 40 rows of sample words leave LDS for five workgroups per CU only without the second texel table */
 {
     constexpr int TILE_PIXELS = TILE_W * TH; /* TH: rows of pixels per tile (FrameParams::tile_h) */
     __shared__ unsigned long long keys[TILE_PIXELS * S];
-    __shared__ ShadeTables tb;
-    __shared__ LevelRec pass_levels[16]; /* the levels of the pass-wide texture, indexable per lane */
+    __shared__ typename std::conditional<SPEC, PassTables, ShadeTables>::type tb;
+    __shared__ LevelRec pass_levels[MAX_TEXTURE_LEVELS]; /* the levels of the pass-wide texture, indexable per lane */
     __shared__ uint4 stage_entry[S == 1 ? TILE_THREADS : 1], stage_corner[S == 1 ? 3 * TILE_THREADS : 1];
     __shared__ signed char wave_rows[TILE_THREADS];
     uint32_t tile, utx, uty;
@@ -1915,7 +1937,7 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 && TH == TILE_H ? TILE_WAVES 
      * shift that scales its byte (taken out of the texel by the instruction's operand selector) and the read. */
     static_assert(offsetof(ShadeTables, value) == 0 && sizeof(float[2][256]) == 128 * 16, "stage_tables swaps the first 2 x 64 pieces");
     stage_tables(tb, fp.tables, fp.pass_texture >= 0 && fp.pass_tex.srgb == 0u);
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < (uint32_t)MAX_TEXTURE_LEVELS) {
         const int lw = (int)level_dim(fp.pass_tex.width, threadIdx.x), lh = (int)level_dim(fp.pass_tex.height, threadIdx.x);
         LevelRec r;
         r.base = reinterpret_cast<unsigned long long>(fp.pass_tex.level[threadIdx.x]);
@@ -2102,6 +2124,19 @@ void launch_tile(const FrameParams& fp, hipStream_t s, uint32_t lds_pad)
      * dummy or the test_ktx shader */
     const bool spec = !getenv_no_spec() && fp.pass_texture >= 0 && (fp.pass_shader == 0 || fp.pass_shader == 1) && fp.pass_tex.filter_linear != 0u && fp.pass_tex.tiled == 0u;
     const dim3 g(grid), b(TILE_THREADS);
+    if (getenv("RND_PRINT_OCCUPANCY")) {
+        /* once per process: how many workgroups of each single-sample instantiation share a CU */
+        static bool printed = false;
+        if (!printed) {
+            printed = true;
+            int n32 = 0, n32s = 0, n40 = 0, n40s = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n32, k_tile<1, TILE_H, false>, TILE_THREADS, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n32s, k_tile<1, TILE_H, true>, TILE_THREADS, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n40, k_tile<1, TILE_H_TALL, false>, TILE_THREADS, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n40s, k_tile<1, TILE_H_TALL, true>, TILE_THREADS, 0);
+            fprintf(stderr, "tile workgroups per CU: 32 rows %d, 32 rows (pass tables) %d, 40 rows %d, 40 rows (pass tables) %d\n", n32, n32s, n40, n40s);
+        }
+    }
     if (fp.samples == 4) {
         if (spec) hipLaunchKernelGGL((k_tile<4, TILE_H, true>), g, b, 0, s, fp, magic);
         else hipLaunchKernelGGL((k_tile<4, TILE_H, false>), g, b, 0, s, fp, magic);
