@@ -128,8 +128,9 @@ __device__ __forceinline__ bool pixel_box(const FrameParams& fp, const RTri& t, 
         x0 = (minx + 127) >> 8; x1 = (maxx - 128) >> 8;
         y0 = (miny + 127) >> 8; y1 = (maxy - 128) >> 8;
     } else {
-        x0 = minx >> 8; x1 = maxx >> 8;
-        y0 = miny >> 8; y1 = maxy >> 8;
+        /* a pixel's samples lie between 1/8 and 7/8 of it on both axes (32 .. 224 of 256): pixels with a sample inside [min, max] */
+        x0 = (minx + 31) >> 8; x1 = (maxx - 32) >> 8;
+        y0 = (miny + 31) >> 8; y1 = (maxy - 32) >> 8;
     }
     x0 = max(x0, fp.clamp_x0); y0 = max(y0, fp.clamp_y0);
     x1 = min(x1, fp.clamp_x1); y1 = min(y1, fp.clamp_y1);
@@ -898,7 +899,7 @@ __device__ __forceinline__ bool tri_box_in_tile(const FrameParams& fp, const Til
     const int minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
     const int miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
     if (fp.samples == 1) { x0 = (minx + 127) >> 8; x1 = (maxx - 128) >> 8; y0 = (miny + 127) >> 8; y1 = (maxy - 128) >> 8; }
-    else { x0 = minx >> 8; x1 = maxx >> 8; y0 = miny >> 8; y1 = maxy >> 8; }
+    else { x0 = (minx + 31) >> 8; x1 = (maxx - 32) >> 8; y0 = (miny + 31) >> 8; y1 = (maxy - 32) >> 8; } /* samples lie at 32 .. 224 of a pixel's 256 */
     x0 = max(x0, tc.rx0); y0 = max(y0, tc.ry0); x1 = min(x1, tc.rx1); y1 = min(y1, tc.ry1);
     return x0 <= x1 && y0 <= y1;
 }
