@@ -1,6 +1,8 @@
 """GPU parity on directed and randomised edge cases: clipping, guard band, large primitives,
 ties in depth, cull state, viewport/scissor/area rectangles, odd target sizes, 4x
 multisampling, sampler modes, target formats, uniform re-read, tile sharding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from renderer_amd import api, hostmath as hm, scenes
 from renderer_amd.runner import SceneRunner
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def gpu_render(scene, device):
@@ -742,3 +745,101 @@ def test_a_pass_without_geometry_reads_zeroed_counters(device, oracle):
             texture.destroy()
         oc, od, _ = oracle.render_scene(sc, threads=4)
         assert np.array_equal(depth, od) and np.array_equal(color, oc)
+
+
+@pytest.mark.parametrize("height", ["40", "32"])
+def test_tile_height_does_not_change_the_frame(device, oracle, height, monkeypatch):
+    """The rows of pixels per tile (32, or 40 for a one-draw mesh on a large target; RND_TILE_HEIGHT, read when a command
+    buffer is recorded, forces one) change how the frame is cut into workgroups, never what is in it: soups over every knob,
+    recorded state cases and a target whose height is a multiple of neither, all against the oracle."""
+    import fuzz_soup
+    import fuzz_state
+    monkeypatch.setenv("RND_TILE_HEIGHT", height)
+    cases = [fuzz_soup.case(s) for s in range(3100, 3112)] + [fuzz_state.case(s) for s in range(200, 208)]
+    cases.append(scenes.config1(333, 217, quads=120, tex_size=64))   # one draw, 217 rows: 5 full rows of 40-row tiles and 17 rows more
+    cases.append(scenes.config0(160, 90, samples=4, tex_size=32, segments=16, rings=8))  # four samples keep 32 rows whatever is asked
+    for k, sc in enumerate(cases):
+        color, depth = gpu_render(sc, device)
+        oc, od, _ = oracle.render_scene(sc, threads=8)
+        ax, ay, aw, ah = sc.area
+        sl = (slice(ay, ay + ah), slice(ax, ax + aw))
+        assert np.array_equal(depth[sl], od[sl]), "case %d: depth differs at %d samples" % (k, int((depth[sl] != od[sl]).sum()))
+        assert np.array_equal(color[sl], oc[sl]), "case %d: colour differs" % k
+
+
+def test_tile_shard_set_after_recording_with_tall_tiles(device, monkeypatch):
+    """Interleaved tile shards count tiles of 32 rows.  A command buffer recorded with 40-row tiles and then given a shard is
+    compiled again with 32 rows: the shards still compose the frame."""
+    monkeypatch.setenv("RND_TILE_HEIGHT", "40")
+    sc = scenes.config1(300, 200, quads=100, tex_size=64)
+    full_c, full_d = gpu_render(sc, device)
+    acc_c, acc_d = np.zeros_like(full_c), np.zeros_like(full_d)
+    tiles_x = (sc.width + 31) // 32
+    shards = 3
+    for k in range(shards):
+        r = SceneRunner(sc, device)          # recorded with 40 rows here ...
+        try:
+            r.cmd.set_tile_shard(k, shards)  # ... and compiled again with 32 by this call
+            c, d = r.render()
+        finally:
+            r.destroy()
+        for ty in range((sc.height + 31) // 32):
+            for tx in range(tiles_x):
+                sl = (slice(ty * 32, ty * 32 + 32), slice(tx * 32, tx * 32 + 32))
+                if (ty * tiles_x + tx) % shards == k:
+                    acc_c[sl], acc_d[sl] = c[sl], d[sl]
+                else:
+                    assert (c[sl] == 0).all()
+    assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
+
+
+def test_more_command_buffers_than_streams(oracle, monkeypatch):
+    """The device keeps a pool of streams for its command buffers (three unless the environment says otherwise); command buffers
+    beyond that share a stream with an earlier one.  Seven command buffers on a pool of two, 40 frames rotating through them
+    with the uniform block rewritten before every submit: each image holds the frame of its last submit."""
+    from renderer_amd import api
+    monkeypatch.setenv("RND_CMD_STREAMS", "2")
+    monkeypatch.setenv("RND_DEBUG_SYNC", "1")
+    dev = api.Device(0)
+    try:
+        sc = scenes.config0(200, 120, tex_size=32, segments=24, rings=12)
+        model = np.asarray(sc.ubos[0][48:64], dtype=np.float32).reshape(4, 4)
+        ubos = []
+        for i in range(5):
+            cam = hm.Camera()
+            cam.eye_position = np.array([0.3 * np.sin(0.9 * i), 0.04 * i, -2.0 - 0.05 * i], dtype=np.float32)
+            ubos.append(hm.global_ubo(cam, model, sc.width, sc.height))
+        r = SceneRunner(sc, dev, frames_in_flight=7)
+        try:
+            owner = {}
+            for i in range(40):
+                r.set_ubo(0, ubos[i % 5])
+                owner[r.submit()] = i
+            dev.wait_idle()
+            got = {img: r.targets[img].read() for img in owner}
+        finally:
+            r.destroy()
+        assert len(owner) == 7
+        for img, frame in owner.items():
+            sc.ubos[0] = ubos[frame % 5]
+            oc, od, _ = oracle.render_scene(sc, threads=4)
+            assert np.array_equal(got[img][1], od) and np.array_equal(got[img][0], oc), "image %d (frame %d) differs" % (img, frame)
+    finally:
+        dev.destroy()
+
+
+def test_general_tile_kernel_renders_the_same_bits(oracle, monkeypatch):
+    """RND_TILE_GENERIC=1 (read once per process by the library, so this test runs the frames in a child process): a pass of
+    the samples' kind rendered by the general instantiation of the tile kernel equals the oracle like the specialised one."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from renderer_amd import scenes; from renderer_amd.runner import SceneRunner; from oracle import oracle\n"
+            "for sc in (scenes.config0(320, 180, tex_size=64, segments=32, rings=16), scenes.config1(240, 136, quads=80, tex_size=64)):\n"
+            "    r = SceneRunner(sc, ordinal=0); c, d = r.render(); r.destroy()\n"
+            "    oc, od, _ = oracle.render_scene(sc, threads=4)\n"
+            "    assert np.array_equal(d, od) and np.array_equal(c, oc), sc.name\n"
+            "print('same bits')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, RND_TILE_GENERIC="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0 and "same bits" in out.stdout, out.stderr[-2000:]
