@@ -267,7 +267,7 @@ struct rnd_cmd_t {
     /* compiled */
     DeviceArray<DrawStatic> d_draws;
     DeviceArray<DrawDerived> d_derived;
-    DeviceArray<Chunk> d_vchunks, d_tchunks;
+    DeviceArray<Chunk> d_vchunks, d_tchunks, d_visible_vchunks, d_visible_tchunks;
     DeviceArray<TexDesc> d_textures;
     DeviceArray<SVtx> d_svtx;
     DeviceArray<SVary> d_svary;
@@ -281,6 +281,7 @@ struct rnd_cmd_t {
     uint32_t shard_index = 0, shard_count = 1;
     uint64_t geometry_epoch = 0;   /* the device's when the draws' boxes were computed */
     uint64_t index_epoch = 0;      /* the device's when the draws' index ranges were scanned */
+    uint64_t frames_submitted = 0; /* its parity picks the pair of visible-list lengths a frame counts into */
 
     void release_compiled()
     {
@@ -330,7 +331,7 @@ struct rnd_cmd_t {
         }
         d_probe.release();
 #endif
-        d_draws.release(); d_derived.release(); d_vchunks.release(); d_tchunks.release(); d_textures.release();
+        d_draws.release(); d_derived.release(); d_vchunks.release(); d_tchunks.release(); d_visible_vchunks.release(); d_visible_tchunks.release(); d_textures.release();
         d_svtx.release(); d_svary.release(); d_prim_rec.release(); d_tile_lists.release(); d_large_list.release(); d_clip_tris.release();
         d_tile_count.release(); d_counters.release();
     }
@@ -1435,6 +1436,7 @@ int rnd_cmd_end(rnd_cmd cmd)
         d.svtx_base = (uint32_t)svtx_total;
         svtx_total += d.vert_count;
         d.prim_base = (uint32_t)prim_total;
+        d.first_tchunk = (uint32_t)tchunks.size();
         prim_total += d.tri_count;
         for (uint32_t v = 0; v < d.vert_count; v += CHUNK) vchunks.push_back(Chunk{(uint32_t)i, v});
         for (uint32_t t = 0; t < d.tri_count; t += CHUNK) tchunks.push_back(Chunk{(uint32_t)i, t});
@@ -1485,6 +1487,13 @@ int rnd_cmd_end(rnd_cmd cmd)
     if (n) HIP_TRY(zero_now(cmd->d_derived.ptr, n * sizeof(DrawDerived), cmd->stream)); /* a draw without vertices is never marked visible */
     HIP_TRY(cmd->d_vchunks.upload(vchunks, cmd->stream));
     HIP_TRY(cmd->d_tchunks.upload(tchunks, cmd->stream));
+    /* RND_COMPACT=0: a pass of many draws keeps one wave per chunk of every draw, visible or not (for A/B runs) */
+    const char* compact_env = getenv("RND_COMPACT");
+    const bool compact = n >= COMPACT_MIN_DRAWS && !(compact_env && atoi(compact_env) == 0);
+    if (compact) {
+        HIP_TRY(cmd->d_visible_vchunks.resize(vchunks.size()));
+        HIP_TRY(cmd->d_visible_tchunks.resize(tchunks.size()));
+    }
     HIP_TRY(cmd->d_textures.upload(td, cmd->stream));
     HIP_TRY(cmd->d_svtx.resize((size_t)svtx_total));
     HIP_TRY(cmd->d_svary.resize((size_t)svtx_total));
@@ -1507,6 +1516,8 @@ int rnd_cmd_end(rnd_cmd cmd)
     memset(&fp, 0, sizeof(fp));
     fp.draws = cmd->d_draws.ptr; fp.derived = cmd->d_derived.ptr;
     fp.vchunks = cmd->d_vchunks.ptr; fp.tchunks = cmd->d_tchunks.ptr; fp.textures = cmd->d_textures.ptr;
+    fp.visible_vchunks = cmd->d_visible_vchunks.ptr; fp.visible_tchunks = cmd->d_visible_tchunks.ptr;
+    fp.compact = compact ? 1u : 0u;
     fp.svtx = cmd->d_svtx.ptr; fp.svary = cmd->d_svary.ptr; fp.prim_rec = cmd->d_prim_rec.ptr;
     fp.tile_count = cmd->d_tile_count.ptr; fp.tile_lists = cmd->d_tile_lists.ptr;
     fp.large_list = cmd->d_large_list.ptr; fp.clip_tris = cmd->d_clip_tris.ptr;
@@ -1565,6 +1576,7 @@ int rnd_submit(rnd_device dev, rnd_cmd cmd, rnd_fence fence)
     fp.shard_index = cmd->shard_index; fp.shard_count = cmd->shard_count;
     /* vertex data written since recording: the boxes no longer bound it, draw everything */
     fp.cull_draws = cmd->geometry_epoch == dev->geometry_epoch ? 1u : 0u;
+    fp.list_parity = (uint32_t)(cmd->frames_submitted++ & 1u);
 #ifdef RND_PROBES
     { const char* dbg = getenv("RND_DEBUG"); fp.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u; }
 #else

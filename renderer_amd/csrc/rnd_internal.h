@@ -23,7 +23,13 @@ constexpr int TILE_PIXELS_MAX = TILE_W * TILE_H_TALL;
 constexpr int TILE_THREADS = TILE_THREADS_N; /* a multiple of 64; a build option: 128 gains 6 % at 4K and costs 38 % at 720p, 192 and 320 lose everywhere */
 constexpr int CHUNK = 64;            /* primitives (or vertices) handled by one wave */
 constexpr int MAX_TILES_PER_PRIM = 16; /* primitives touching more tiles go to the pass-wide list */
-enum : uint32_t { CTR_LARGE = 0, CTR_CLIP_TRIS = 1, CTR_OVERFLOW = 2, CTR_COUNT = 3 };
+/* Words 0..2 are zeroed by each frame's vertex kernel.  Words 3..6 are the lengths of the lists of visible chunks
+ * (vertex chunks, primitive chunks) that the per-draw kernel of a pass of many draws builds: two pairs, used by
+ * alternate frames, so that a frame's per-draw kernel can zero the pair the next frame will count into. */
+enum : uint32_t { CTR_LARGE = 0, CTR_CLIP_TRIS = 1, CTR_OVERFLOW = 2, CTR_FRAME_COUNT = 3, CTR_VISIBLE = 3, CTR_COUNT = 7 };
+/* a pass of at least this many draws gets the per-draw kernel, which leaves the chunks of the draws it found visible in
+ * two dense lists; the vertex and setup kernels then run over those with a fixed grid, and a culled draw costs them nothing */
+constexpr uint32_t COMPACT_MIN_DRAWS = 256;
 enum : uint32_t { OVF_LARGE = 1, OVF_CLIP_TRIS = 4 };
 constexpr int TILE_COUNT_STRIDE = 32; /* one tile counter per 128-byte line: atomics on neighbouring tiles do not share a line */
 constexpr int MAX_TILE_AXIS = 256;   /* tile coordinates are packed in 8 bits */
@@ -142,7 +148,8 @@ struct DrawStatic {
     uint32_t has_bounds; /* bounds_min / bounds_max hold the box of the draw's vertices (all finite) */
     float push[20];      /* vec4 colour, mat4 transform */
     float bounds_min[3], bounds_max[3]; /* object space, over vertices [0, vert_count) */
-    uint32_t pad1[2];
+    uint32_t first_tchunk; /* number, within the pass, of the draw's first chunk of 64 primitives: chunk k of the pass owns primitive slots 64k .. 64k+63 */
+    uint32_t pad1;
 };
 
 /* Per draw, derived from the uniform buffer each time the work executes: object space to clip space (for the
@@ -225,6 +232,8 @@ struct FrameParams {
     DrawDerived* derived;
     const Chunk* vchunks;
     const Chunk* tchunks;
+    Chunk* visible_vchunks;  /* compact != 0: the chunks of the draws this frame found visible, dense, in no particular order; */
+    Chunk* visible_tchunks;  /* their lengths are counters[CTR_VISIBLE + 2 * list_parity + 0 / 1] */
     const TexDesc* textures;
     SVtx* svtx;
     struct SVary* svary;     /* per vertex: the vertex shader's other outputs */
@@ -253,6 +262,8 @@ struct FrameParams {
      * box of vertices lies wholly beyond one of these four planes, the near plane or the far plane has no
      * fragment inside the rectangle (a device that renders one band of a frame skips the other bands' draws) */
     float cull_lo_x, cull_hi_x, cull_lo_y, cull_hi_y;
+    uint32_t compact;        /* 1: the pass has COMPACT_MIN_DRAWS draws or more */
+    uint32_t list_parity;    /* which pair of list lengths this frame uses: alternates between successive frames of the command buffer */
     uint32_t cull_draws;     /* 0: the boxes are stale (vertex data was written after recording), nothing is culled */
     int32_t clamp_x0, clamp_y0, clamp_x1, clamp_y1; /* inclusive pixel rectangle fragments may land in */
     int32_t area_x0, area_y0, area_x1, area_y1;     /* inclusive render area (cleared and stored) */

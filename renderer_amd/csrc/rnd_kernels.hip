@@ -1,7 +1,9 @@
 /*
  * rnd_kernels.hip -- gfx950 kernels of the draw path.
  *
- * One submit of a recorded pass runs three kernels:
+ * One submit of a recorded pass runs three kernels, after a fourth in a pass of many draws or many vertices:
+ *   k_draws      one lane per draw: the draw's matrices and whether its box can show at all; in a pass of
+ *                many draws also the dense lists of the visible draws' chunks, which the next two walk
  *   k_vertex     vertex fetch, the draw's matrices built per wave from the uniform buffer as it
  *                is at execution time (base_obj_viewer_app.cpp:134-138) and the push constants,
  *                position shader, clip codes, viewport, 24.8 snap
@@ -215,29 +217,48 @@ __device__ __forceinline__ float uniform_read(const UniformPatch& up, const floa
     return load_f32(p);
 }
 
+/* the same without a branch, for a lane that reads many floats in a row: both places are always readable (the kernel's
+ * arguments; the uniform buffer, whose range was checked when the draw was recorded), so the loads all go out together
+ * instead of each waiting behind the previous one's branch */
+__device__ __forceinline__ float uniform_read_both(const UniformPatch& up, const float* p)
+{
+    const size_t off = (size_t)(reinterpret_cast<const uint8_t*>(p) - up.dst);
+    const bool patched = up.dst && off < (size_t)up.bytes;
+    typedef const __attribute__((address_space(4))) uint32_t* KernargWords;
+    KernargWords w = (KernargWords)((const __attribute__((address_space(4))) uint8_t*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                    offsetof(VertexArgs, up) + offsetof(UniformPatch, words));
+    const uint32_t from_patch = w[patched ? off >> 2 : 0];
+    const float from_memory = load_f32(p);
+    return patched ? __uint_as_float(from_patch) : from_memory;
+}
+
 __device__ __forceinline__ float lane_value(float v, int lane)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-/* The draw's matrices, built by the wave from the uniform buffer as it is when the frame executes
- * (base_obj_viewer_app.cpp:126-138 writes it every frame): clip_m = mvp * push.transform and the
- * normal matrix inverse(transpose(mat3(model * push.transform))) (test_ktx.vert:28-30); the dummy
- * shader uses mvp alone (dummy.vert.glsl:22).  Lane k < 16 computes element k of the first product,
- * lane 16 + k element k of the second, each as the same four-term multiply-add chain a scalar
- * implementation runs; the results are then broadcast. */
-__device__ __forceinline__ float wave_matrix_element(const UniformPatch& up, const DrawStatic& d, int shader, const float* ubo)
+/* Element k (column-major) of a draw's matrix A * push.transform, A being the 4x4 at `a` in the uniform buffer as it
+ * is when the frame executes (base_obj_viewer_app.cpp:126-138 writes it every frame): clip_m = mvp * push.transform,
+ * and the normal matrix is inverse(transpose(mat3(model * push.transform))) (test_ktx.vert:28-30).  The dummy shader
+ * uses mvp alone (dummy.vert.glsl:22).  One four-term multiply-add chain per element, whoever runs it. */
+__device__ __forceinline__ float matrix_element(const UniformPatch& up, const DrawStatic& d, int shader, const float* a, uint32_t k)
 {
-    const uint32_t lane = lane_id();
-    const uint32_t k = lane & 15u, row = k & 3u, col = k >> 2;
-    if (shader == 0) return uniform_read(up, ubo + 64 + k);
-    const float* a = ubo + ((lane & 16u) ? 48 : 64); /* model : mvp */
+    const uint32_t row = k & 3u, col = k >> 2;
+    if (shader == 0) return uniform_read(up, a + k);
     const float* b = d.push + 4 + col * 4;
     float acc = uniform_read(up, a + 0 * 4 + row) * b[0];
     acc = fma32(uniform_read(up, a + 1 * 4 + row), b[1], acc);
     acc = fma32(uniform_read(up, a + 2 * 4 + row), b[2], acc);
     acc = fma32(uniform_read(up, a + 3 * 4 + row), b[3], acc);
     return acc;
+}
+
+/* The same built by a wave for its own use: lane k < 16 computes element k of mvp * transform, lane 16 + k element k
+ * of model * transform; the results are then broadcast. */
+__device__ __forceinline__ float wave_matrix_element(const UniformPatch& up, const DrawStatic& d, int shader, const float* ubo)
+{
+    const uint32_t lane = lane_id();
+    return matrix_element(up, d, shader, ubo + ((lane & 16u) && shader != 0 ? 48 : 64), lane & 15u); /* model : mvp */
 }
 
 /* object space -> clip space, from lanes 0..15 */
@@ -269,14 +290,13 @@ __device__ __forceinline__ void wave_normal_matrix(int shader, float element, fl
  * same plane out of the rectangle's four (grown by a pixel), near and far.  A plane function is affine
  * in the object-space position, so its largest value over the box is at a corner; a corner counts as
  * beyond a plane only by more than TOL times the sum of the magnitudes that went into the function,
- * which covers the rounding of this evaluation and of the vertices' own transform.  Lane k < 8 takes
- * corner k; the answer is the same in every lane. */
-__device__ __forceinline__ bool draw_is_outside(const FrameParams& fp, const DrawStatic& d, const float* m)
+ * which covers the rounding of this evaluation and of the vertices' own transform.  corner_beyond gives,
+ * for one corner, a bit per plane. */
+__device__ __forceinline__ uint32_t corner_beyond(const FrameParams& fp, const DrawStatic& d, const float* m, uint32_t corner)
 {
     constexpr float TOL = 1.0e-5f;
-    const uint32_t lane = lane_id();
-    const float p[3] = {(lane & 1u) ? d.bounds_max[0] : d.bounds_min[0], (lane & 2u) ? d.bounds_max[1] : d.bounds_min[1],
-                        (lane & 4u) ? d.bounds_max[2] : d.bounds_min[2]};
+    const float p[3] = {(corner & 1u) ? d.bounds_max[0] : d.bounds_min[0], (corner & 2u) ? d.bounds_max[1] : d.bounds_min[1],
+                        (corner & 4u) ? d.bounds_max[2] : d.bounds_min[2]};
     float clip[4], mag[4];
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
@@ -286,74 +306,161 @@ __device__ __forceinline__ bool draw_is_outside(const FrameParams& fp, const Dra
     clip[1] = 1.0f - clip[1];
     mag[1] = mag[1] + 1.0f;
     const float x = clip[0], y = clip[1], z = clip[2], w = clip[3];
-    bool out[6];
-    out[0] = fma32(-fp.cull_lo_x, w, x) < -TOL * fma32(fabsf(fp.cull_lo_x), mag[3], mag[0]);
-    out[1] = fma32(fp.cull_hi_x, w, -x) < -TOL * fma32(fabsf(fp.cull_hi_x), mag[3], mag[0]);
-    out[2] = fma32(-fp.cull_lo_y, w, y) < -TOL * fma32(fabsf(fp.cull_lo_y), mag[3], mag[1]);
-    out[3] = fma32(fp.cull_hi_y, w, -y) < -TOL * fma32(fabsf(fp.cull_hi_y), mag[3], mag[1]);
-    out[4] = z < -TOL * mag[2];
-    out[5] = w - z < -TOL * (mag[3] + mag[2]);
+    uint32_t out = 0u;
+    out |= fma32(-fp.cull_lo_x, w, x) < -TOL * fma32(fabsf(fp.cull_lo_x), mag[3], mag[0]) ? 1u : 0u;
+    out |= fma32(fp.cull_hi_x, w, -x) < -TOL * fma32(fabsf(fp.cull_hi_x), mag[3], mag[0]) ? 2u : 0u;
+    out |= fma32(-fp.cull_lo_y, w, y) < -TOL * fma32(fabsf(fp.cull_lo_y), mag[3], mag[1]) ? 4u : 0u;
+    out |= fma32(fp.cull_hi_y, w, -y) < -TOL * fma32(fabsf(fp.cull_hi_y), mag[3], mag[1]) ? 8u : 0u;
+    out |= z < -TOL * mag[2] ? 16u : 0u;
+    out |= w - z < -TOL * (mag[3] + mag[2]) ? 32u : 0u;
+    return out;
+}
+
+/* by a wave: lane k < 8 takes corner k; the answer is the same in every lane */
+__device__ __forceinline__ bool draw_is_outside(const FrameParams& fp, const DrawStatic& d, const float* m)
+{
+    const uint32_t mine = corner_beyond(fp, d, m, lane_id() & 7u);
     bool outside = false;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) outside = outside || (__ballot(out[k]) & 0xFFull) == 0xFFull;
+    for (int k = 0; k < 6; ++k) outside = outside || (__ballot((mine >> k) & 1u) & 0xFFull) == 0xFFull;
     return outside;
 }
 
-/* A pass of many small draws: one wave per DRAW builds what the draw's vertex waves would each build again
- * (a draw of 162 vertices has three of them, and the matrices are most of such a wave's instructions) -- the
- * two matrices and the verdict on the draw's box.  The vertex kernel then starts from three scalar loads, and
- * a culled draw costs each of its waves one of them. */
-constexpr uint32_t PER_DRAW_KERNEL_MIN_DRAWS = 256;
-/* ... and a pass of few draws with many vertices: every vertex wave builds its draw's matrices again (two thirds of
+/* by one lane, corner after corner */
+__device__ __forceinline__ bool draw_is_outside_lane(const FrameParams& fp, const DrawStatic& d, const float* m)
+{
+    uint32_t all = 63u;
+    for (uint32_t corner = 0; corner < 8u; ++corner) all &= corner_beyond(fp, d, m, corner);
+    return all != 0u;
+}
+
+/* ... and a pass of few draws with many vertices: every vertex wave would build its draw's matrices again (two thirds of
  * such a wave's vector instructions), which for some thousand waves is more than the extra launch costs */
 constexpr uint32_t PER_DRAW_KERNEL_MIN_WAVES = 2048;
 
-__global__ __launch_bounds__(256) void k_draws(VertexArgs args)
+/* `count` chunks of 64 (vertices or primitives) of this lane's draw join the dense list: the wave takes one range of
+ * the list for all its draws, with one atomic, and each lane writes its draw's chunks -- a draw of very many chunks
+ * has them written by the whole wave. */
+__device__ __forceinline__ void append_chunks(Chunk* list, uint32_t* length, uint32_t draw, uint32_t count)
 {
-    const FrameParams& fp = args.fp;
-    const uint32_t draw = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (draw >= fp.n_draws) return;
-    const DrawStatic& d = fp.draws[draw];
-    float m[16], nm[9];
-    const float mine = wave_matrix_element(args.up, d, d.shader, d.ubo);
-    wave_clip_matrix(mine, m);
-    bool outside = d.vert_count == 0u;
-    if (d.has_bounds != 0u && fp.cull_draws != 0u) outside = outside || draw_is_outside(fp, d, m);
-    DrawDerived& out = fp.derived[draw];
-    if (lane_id() == 0) out.visible = outside ? 0u : 1u;
-    if (outside) return;
-    wave_normal_matrix(d.shader, mine, nm);
-    if (lane_id() < 16u) out.clip_m[lane_id()] = mine;
+    const uint32_t lane = lane_id();
+    uint32_t incl = count;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) if (lane_id() == (uint32_t)i) out.nrm_m[i] = nm[i];
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t below = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= (uint32_t)d) incl += below;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (!total) return;
+    uint32_t base = 0u;
+    if (lane == 0u) base = atomicAdd(length, total);
+    base = wave_uniform(base);
+    const uint32_t at = base + incl - count;
+    constexpr uint32_t FEW = 8u;
+    if (count <= FEW)
+        for (uint32_t j = 0; j < count; ++j) list[at + j] = Chunk{draw, j * 64u};
+    uint64_t many = __ballot(count > FEW);
+    while (many) {
+        const int l = __ffsll((unsigned long long)many) - 1;
+        many &= many - 1ull;
+        const uint32_t n = (uint32_t)__shfl((int)count, l), first = (uint32_t)__shfl((int)at, l), dr = (uint32_t)__shfl((int)draw, l);
+        for (uint32_t j = lane; j < n; j += 64u) list[first + j] = Chunk{dr, j * 64u};
+    }
 }
 
-/* One wave per chunk of 64 vertices of one draw.  PREPARED: k_draws has run. */
+/* A pass of many small draws, or of many vertex waves: one LANE per draw builds what the draw's vertex waves would each
+ * build again (a draw of 162 vertices has three of them, and the matrices are most of such a wave's instructions) -- the
+ * two matrices and the verdict on the draw's box.  The vertex kernel then starts from scalar loads.  In a pass of many
+ * draws the chunks of the visible ones also go to two dense lists, which the vertex and setup kernels walk: a culled draw
+ * costs them nothing (a device that renders one band of a frame culls most of the pass). */
+constexpr uint32_t DRAWS_THREADS = 64; /* one wave per workgroup: a pass of 10 000 draws is then spread over 157 CUs instead of 40 */
+__global__ __launch_bounds__(DRAWS_THREADS) void k_draws(VertexArgs args)
+{
+    const FrameParams& fp = args.fp;
+    const uint32_t draw = blockIdx.x * DRAWS_THREADS + threadIdx.x;
+    uint32_t* lengths = fp.counters + CTR_VISIBLE + 2u * fp.list_parity;
+    /* the pair of lengths the previous frame counted into is the next frame's: that frame's kernels have all finished */
+    if (fp.compact && blockIdx.x == 0u && threadIdx.x < 2u) fp.counters[CTR_VISIBLE + 2u * (fp.list_parity ^ 1u) + threadIdx.x] = 0u;
+    uint32_t n_v = 0u, n_t = 0u;
+    if (draw < fp.n_draws) {
+        const DrawStatic& d = fp.draws[draw];
+        const int shader = d.shader;
+        const float* ubo = d.ubo;
+        /* everything the lane reads, requested at once: mvp, the model matrix's three rows, the draw's transform */
+        float mvp[16], model[16], tr[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mvp[k] = uniform_read_both(args.up, ubo + 64 + k);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) model[k] = (k & 3) < 3 && shader != 0 ? uniform_read_both(args.up, ubo + 48 + k) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tr[k] = d.push[4 + k];
+        /* element k = row + 4 * col of A * transform: the four-term chain of matrix_element */
+        auto product = [&tr](const float* a, int k) -> float {
+            const int row = k & 3, col = k >> 2;
+            float acc = a[0 * 4 + row] * tr[col * 4 + 0];
+            acc = fma32(a[1 * 4 + row], tr[col * 4 + 1], acc);
+            acc = fma32(a[2 * 4 + row], tr[col * 4 + 2], acc);
+            acc = fma32(a[3 * 4 + row], tr[col * 4 + 3], acc);
+            return acc;
+        };
+        float m[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m[k] = shader == 0 ? mvp[k] : product(mvp, k);
+        bool outside = d.vert_count == 0u;
+        if (d.has_bounds != 0u && fp.cull_draws != 0u) outside = outside || draw_is_outside_lane(fp, d, m);
+        DrawDerived& out = fp.derived[draw];
+        out.visible = outside ? 0u : 1u;
+        if (!outside) {
+            float nm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) nm[i] = 0.0f;
+            if (shader != 0) {
+                float mt[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) mt[k] = (k & 3) < 3 && k < 12 ? product(model, k) : 0.0f;
+                normal_matrix(mt, nm);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) out.clip_m[i] = m[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) out.nrm_m[i] = nm[i];
+            n_v = (d.vert_count + 63u) / 64u;
+            n_t = (d.tri_count + 63u) / 64u;
+        }
+    }
+    if (!fp.compact) return;
+    append_chunks(fp.visible_vchunks, &lengths[0], draw, n_v);
+    append_chunks(fp.visible_tchunks, &lengths[1], draw, n_t);
+}
+
+/* Tables that no kernel of the frame writes while this one runs, read through the constant address space: a wave-uniform
+ * address there is always a scalar load, also after the kernel's own stores (a kernel that walks a list of chunks has
+ * stored the previous chunk's vertices when it reads the next chunk's draw) */
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* constant_table(const T* p)
+{
+    return (const __attribute__((address_space(4))) T*)reinterpret_cast<uintptr_t>(p);
+}
+
+/* One wave, one chunk of 64 vertices of one draw.  PREPARED: k_draws has run. */
 template <bool PREPARED>
-__global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
+__device__ __forceinline__ void vertex_chunk(const VertexArgs& args, Chunk c)
 {
     const FrameParams& fp = args.fp;
     const UniformPatch& up = args.up;
-    RND_KERNEL_BEGIN(fp, 0);
-    const uint32_t chunk = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (chunk >= fp.n_vchunks) return;
-    Chunk c = {0u, chunk * 64u}; /* what the chunk table of a one-draw pass holds */
-    if (!fp.direct_index) c = fp.vchunks[chunk];
-    /* The chunk is the same for the whole wave, and said so; and the draw's record is copied here, before the kernel's
+    /* The chunk is the same for the whole wave, and said so; and the draw's record is copied here, before the wave's
      * first store.  Both are needed for the record to be read with scalar loads, all at once: a field read after a
      * store that might have changed it is read with a vector load of its own, and the kernel began with six of those in
      * a row, each waiting for the one before. */
     c.draw = wave_uniform(c.draw); c.first = wave_uniform(c.first);
     const DrawStatic& dm = fp.draws[c.draw]; /* the record in memory: what is indexed per lane (push constants, box) */
+    const auto* dk = constant_table(fp.draws) + c.draw;
     struct {
         const uint8_t* vb; const float* ubo; uint32_t stride; int32_t off_pos, off_nrm, off_uv; int32_t shader;
         uint32_t vert_count, svtx_base, has_bounds;
-    } const d = {dm.vb, dm.ubo, dm.stride, dm.off_pos, dm.off_nrm, dm.off_uv, dm.shader, dm.vert_count, dm.svtx_base, dm.has_bounds};
+    } const d = {dk->vb, dk->ubo, dk->stride, dk->off_pos, dk->off_nrm, dk->off_uv, dk->shader, dk->vert_count, dk->svtx_base, dk->has_bounds};
     uint32_t visible = 1u;
-    if constexpr (PREPARED) visible = fp.derived[c.draw].visible;
-    /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel
-     * (the first three threads of the grid belong to chunk 0, which every launch has) */
-    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) fp.counters[threadIdx.x] = 0;
+    if constexpr (PREPARED) visible = constant_table(fp.derived)[c.draw].visible;
     float m[16], nm[9], mine = 0.0f;
     if (!visible) return;
     const bool cullable = !PREPARED && d.has_bounds != 0u && fp.cull_draws != 0u;
@@ -402,11 +509,11 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     }
     if constexpr (PREPARED) {
         /* wave-uniform addresses: scalar loads */
-        const DrawDerived& dd = fp.derived[c.draw];
+        const auto* dd = constant_table(fp.derived) + c.draw;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m[i] = dd.clip_m[i];
+        for (int i = 0; i < 16; ++i) m[i] = dd->clip_m[i];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) nm[i] = dd.nrm_m[i];
+        for (int i = 0; i < 9; ++i) nm[i] = dd->nrm_m[i];
     } else {
         if (!test_first) {
             mine = wave_matrix_element(up, dm, d.shader, d.ubo);
@@ -451,6 +558,33 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
         vo.light = fma32(tn[2], lz, fma32(tn[1], ly, tn[0] * lx));
     }
     fp.svary[d.svtx_base + v] = vo;
+}
+
+/* how many workgroups walk a dense list of chunks: enough to fill every CU at full occupancy, no more */
+constexpr uint32_t LIST_WALK_BLOCKS = 256u * 8u;
+
+/* One wave per chunk of 64 vertices; COMPACT: the waves of a fixed grid share out the list of visible chunks. */
+template <bool PREPARED, bool COMPACT>
+__global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
+{
+    const FrameParams& fp = args.fp;
+    RND_KERNEL_BEGIN(fp, 0);
+    /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel */
+    if (blockIdx.x == 0 && threadIdx.x < CTR_FRAME_COUNT) fp.counters[threadIdx.x] = 0;
+    const uint32_t wave = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if constexpr (COMPACT) {
+        const uint32_t listed = min(constant_table(fp.counters)[CTR_VISIBLE + 2u * fp.list_parity], fp.n_vchunks);
+        const auto* list = constant_table(fp.visible_vchunks);
+        for (uint32_t i = wave; i < listed; i += gridDim.x * 4u) {
+            const Chunk c = {list[i].draw, list[i].first};
+            vertex_chunk<true>(args, c);
+        }
+    } else {
+        if (wave >= fp.n_vchunks) return;
+        Chunk c = {0u, wave * 64u}; /* what the chunk table of a one-draw pass holds */
+        if (!fp.direct_index) c = fp.vchunks[wave];
+        vertex_chunk<PREPARED>(args, c);
+    }
     RND_KERNEL_END(fp, 0u);
 }
 
@@ -611,23 +745,10 @@ __device__ __forceinline__ void clip_primitive(const FrameParams& fp, const Draw
     }
 }
 
-/* One wave per chunk of 64 primitives of one draw: fetch, classify, cull and orient, bin; then
- * clip the few that need it. */
-__global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
+/* One wave, one chunk of 64 primitives of one draw (chunk number `chunk` of the pass: its primitives own slots
+ * 64 * chunk ..): fetch, classify, cull and orient, bin; then clip the few that need it. */
+__device__ __forceinline__ void setup_chunk(const FrameParams& fp, uint32_t chunk, Chunk c, float (*clip_lds)[CLIP_LDS_FLOATS])
 {
-    __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
-    RND_KERNEL_BEGIN(fp, 1);
-    /* Workgroups are dealt round-robin over the 8 XCDs.  In a pass of one draw -- a mesh, whose neighbouring chunks of
-     * primitives share vertices and append to the same tile lists -- each XCD takes a contiguous eighth of the chunks, so
-     * that neighbours meet in one L2 (the grid is then a multiple of 8 workgroups).  A pass of many small draws keeps
-     * the plain order: measured slower there, its draws being scattered over the screen anyway. */
-    uint32_t block = blockIdx.x;
-    if (fp.direct_index) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t chunk = wave_uniform(block * 4u + (threadIdx.x >> 6));
-    if (chunk >= fp.n_tchunks) return;
-    /* a pass without a chunk table is one draw whose chunks are its triangles in order */
-    const Chunk c = fp.tchunks ? fp.tchunks[chunk] : Chunk{0u, chunk * 64u};
-    if (!fp.derived[c.draw].visible) return; /* the vertex kernel found the draw's box outside what this device renders */
     const DrawStatic& d = fp.draws[c.draw];
     const uint32_t lane = lane_id();
     const uint32_t tri = c.first + lane;
@@ -665,7 +786,6 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
 
     /* Primitives that cross the near plane, the far plane or the guard band (rare): the wave clips
      * them CLIP_LANES at a time, lane j taking the j-th of them, with the polygons in LDS. */
-    RND_KERNEL_END(fp, (fp.n_vchunks + 3u) / 4u);
     uint64_t cm = __ballot(needs_clip);
     if (!cm) return;
     ClipStore st;
@@ -683,6 +803,36 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
                        i2 = (uint32_t)__shfl((int)pf.idx[2], from);
         if (src >= 0 && lane < (uint32_t)CLIP_LANES) clip_primitive(fp, d, c.draw, chunk * 64u + (uint32_t)src, i0, i1, i2, st);
     }
+}
+
+/* One wave per chunk of 64 primitives; COMPACT: the waves of a fixed grid share out the list of visible chunks. */
+template <bool COMPACT>
+__global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
+{
+    __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
+    RND_KERNEL_BEGIN(fp, 1);
+    if constexpr (COMPACT) {
+        const uint32_t listed = min(constant_table(fp.counters)[CTR_VISIBLE + 2u * fp.list_parity + 1u], fp.n_tchunks);
+        const auto* list = constant_table(fp.visible_tchunks);
+        for (uint32_t i = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6)); i < listed; i += gridDim.x * 4u) {
+            const Chunk c = {wave_uniform(list[i].draw), wave_uniform(list[i].first)};
+            setup_chunk(fp, constant_table(fp.draws)[c.draw].first_tchunk + c.first / 64u, c, clip_lds);
+        }
+    } else {
+        /* Workgroups are dealt round-robin over the 8 XCDs.  In a pass of one draw -- a mesh, whose neighbouring chunks of
+         * primitives share vertices and append to the same tile lists -- each XCD takes a contiguous eighth of the chunks, so
+         * that neighbours meet in one L2 (the grid is then a multiple of 8 workgroups).  A pass of many small draws keeps
+         * the plain order: measured slower there, its draws being scattered over the screen anyway. */
+        uint32_t block = blockIdx.x;
+        if (fp.direct_index) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        const uint32_t chunk = wave_uniform(block * 4u + (threadIdx.x >> 6));
+        if (chunk >= fp.n_tchunks) return;
+        /* a pass without a chunk table is one draw whose chunks are its triangles in order */
+        const Chunk c = fp.tchunks ? fp.tchunks[chunk] : Chunk{0u, chunk * 64u};
+        if (!fp.derived[c.draw].visible) return; /* the draw's box lies outside what this device renders */
+        setup_chunk(fp, chunk, c, clip_lds);
+    }
+    RND_KERNEL_END(fp, (fp.n_vchunks + 3u) / 4u);
 }
 
 /* ------------------------------------------------------------------ tile kernel */
@@ -2084,17 +2234,27 @@ void launch_bounds(const BoundsJob* jobs, uint32_t* out_min_max, uint32_t n_jobs
     hipLaunchKernelGGL(k_bounds, dim3(64, n_jobs), dim3(256), 0, s, jobs, out_min_max);
 }
 
+/* RND_LIST_WALK_BLOCKS=n: the grid that walks a list of visible chunks has at most n workgroups (for A/B runs) */
+static uint32_t list_walk_blocks()
+{
+    static const uint32_t v = [] { const char* e = getenv("RND_LIST_WALK_BLOCKS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : LIST_WALK_BLOCKS; }();
+    return v;
+}
+
 void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t s)
 {
     const uint32_t blocks = (fp.n_vchunks + 3) / 4;
     if (!blocks) return;
     VertexArgs args;
     args.fp = fp; args.up = patch;
-    if (fp.n_draws >= PER_DRAW_KERNEL_MIN_DRAWS || fp.n_vchunks >= PER_DRAW_KERNEL_MIN_WAVES) {
-        hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + 3) / 4), dim3(256), 0, s, args);
-        hipLaunchKernelGGL(k_vertex<true>, dim3(blocks), dim3(256), 0, s, args);
+    if (fp.compact) {
+        hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + DRAWS_THREADS - 1) / DRAWS_THREADS), dim3(DRAWS_THREADS), 0, s, args);
+        hipLaunchKernelGGL((k_vertex<true, true>), dim3(blocks < list_walk_blocks() ? blocks : list_walk_blocks()), dim3(256), 0, s, args);
+    } else if (fp.n_vchunks >= PER_DRAW_KERNEL_MIN_WAVES) {
+        hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + DRAWS_THREADS - 1) / DRAWS_THREADS), dim3(DRAWS_THREADS), 0, s, args);
+        hipLaunchKernelGGL((k_vertex<true, false>), dim3(blocks), dim3(256), 0, s, args);
     } else {
-        hipLaunchKernelGGL(k_vertex<false>, dim3(blocks), dim3(256), 0, s, args);
+        hipLaunchKernelGGL((k_vertex<false, false>), dim3(blocks), dim3(256), 0, s, args);
     }
 }
 
@@ -2103,7 +2263,8 @@ void launch_setup(const FrameParams& fp, hipStream_t s)
     if (!fp.n_tchunks) return;
     uint32_t blocks = (fp.n_tchunks + 3) / 4;
     if (fp.direct_index) blocks = ((blocks + 7) / 8) * 8; /* one share per XCD */
-    hipLaunchKernelGGL(k_setup, dim3(blocks), dim3(256), 0, s, fp);
+    if (fp.compact) hipLaunchKernelGGL(k_setup<true>, dim3(blocks < list_walk_blocks() ? blocks : list_walk_blocks()), dim3(256), 0, s, fp);
+    else hipLaunchKernelGGL(k_setup<false>, dim3(blocks), dim3(256), 0, s, fp);
 }
 
 /* RND_TILE_GENERIC=1: every pass takes the general instantiation of the tile kernel (for A/B runs and the tests) */

@@ -546,6 +546,61 @@ def test_scissored_pass_skips_draws_and_tiles_outside(device, oracle, grid):
     assert 0 < visible < len(sc.draws) // 2
 
 
+def test_lists_of_visible_chunks(device, oracle):
+    """A pass of several hundred draws: the per-draw kernel leaves the chunks of the visible draws in dense lists that
+    the vertex and setup kernels walk.  Small spheres (3 chunks of vertices, 5 of primitives each: written by the draw's
+    lane) among a few instances of a mesh of 2562 vertices and 5120 triangles (41 and 80 chunks: written by the whole
+    wave), one of them off screen, plus a draw of a single triangle; three frames of one command buffer with the camera
+    moved between them, so that the visible set and the pair of list lengths in use both change; then bands."""
+    from renderer_amd import sharding
+    width, height = 320, 224
+    sc = scenes.instanced_spheres(width, height, 12, 9, 3, 17, tex_size=32)
+    v, i = scenes.icosphere(4, radius=1.0)
+    sc.vbs.append(v)
+    sc.ibs.append(i)
+    base = sc.draws[0]
+
+    def big(tx, ty, tz, s, at):
+        m = hm.scale(hm.translate(hm.identity(), [tx, ty, tz]), [s, s, s])
+        d = dict(base, vb=1, ib=1, index_count=int(i.size), push=scenes.push_block([0.3, 0.8, 0.4, 1.0], m))
+        sc.draws.insert(at, d)
+
+    big(0.3, 1.2, 0.6, 0.9, 40)     # in view, among the small ones in submission order
+    big(60.0, 1.0, 0.0, 1.0, 41)    # far to the right: culled
+    big(-2.6, 0.2, 0.2, 0.8, 200)   # across the left edge
+    one = dict(base, index_count=3, first_index=30)
+    sc.draws.insert(100, one)
+    assert len(sc.draws) >= 256
+    r = SceneRunner(sc, device)
+    try:
+        seen = []
+        for eye in ([0.0, 0.0, -2.0], [1.5, 0.4, -1.2], [-2.5, -0.8, -2.4]):
+            cam = hm.Camera()
+            cam.eye_position = np.array(eye, dtype=np.float32)
+            sc.ubos[0] = hm.global_ubo(cam, hm.identity(), width, height)
+            r.set_ubo(0, sc.ubos[0])
+            color, depth = r.render()
+            seen.append(r.cmd.visible_draws())
+            oc, od, _ = oracle.render_scene(sc, threads=8)
+            assert np.array_equal(depth, od) and np.array_equal(color, oc), eye
+    finally:
+        r.destroy()
+    assert len(set(seen)) > 1 and all(0 < n < len(sc.draws) for n in seen)
+    full_c, full_d = color, depth
+    acc_c, acc_d = np.zeros_like(full_c), np.zeros_like(full_d)
+    for k in range(4):
+        y0, y1 = sharding.band_rows(height, k, 4)
+        r = SceneRunner(sharding.band_scene(sc, k, 4), device)
+        try:
+            c, d = r.render()
+            c2, d2 = r.render()  # the other pair of list lengths
+        finally:
+            r.destroy()
+        assert np.array_equal(c, c2) and np.array_equal(d, d2)
+        acc_c[y0:y1], acc_d[y0:y1] = c[y0:y1], d[y0:y1]
+    assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
+
+
 def test_resubmission_is_idempotent(device):
     sc = helpers.soup_scene(200, 150, 2000, 77, depth_levels=2, n_draws=7)
     r = SceneRunner(sc, device)
