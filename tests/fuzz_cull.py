@@ -33,7 +33,17 @@ def case(seed):
     sc.ubos[0] = hm.global_ubo(cam, model, w, h)
     base = sc.draws[0]
     sc.draws = []
-    for _ in range(int(rng.randint(2, 40))):
+    n_draws = int(rng.randint(2, 40))
+    big = None
+    if seed % 5 == 4:
+        # a pass of hundreds of draws: the per-draw kernel lists the chunks of the visible ones, and the vertex and
+        # setup kernels walk the lists; some draws of a mesh of 41 / 80 chunks, whose chunks the whole wave lists
+        n_draws = int(rng.randint(256, 600))
+        v, i = scenes.icosphere(4, radius=1.0)
+        sc.vbs.append(v)
+        sc.ibs.append(i)
+        big = dict(base, vb=1, ib=1, index_count=int(i.size))
+    for k in range(n_draws):
         kind = rng.randint(0, 6)
         s = float(np.exp(rng.uniform(np.log(0.05), np.log(3.0))))
         t = rng.uniform(-1, 1, size=3) * [4.0, 4.0, 3.0]
@@ -47,7 +57,7 @@ def case(seed):
             t[2] = rng.uniform(60, 140)    # around the far plane
         m = hm.translate(hm.identity(), [float(t[0]), float(1.0 + t[1]), float(t[2])])
         m = hm.scale(m, [s, s * float(rng.uniform(0.3, 1.5)), s])
-        d = dict(base)
+        d = dict(big if big is not None and k % 97 == 5 else base)
         d["push"] = scenes.push_block([rng.rand(), rng.rand(), rng.rand(), 1.0], m)
         if shader == scenes.SHADER_PUSH_CONSTANTS:
             d["texture"] = -1
@@ -74,6 +84,11 @@ def main():
         try:
             color, depth = r.render()
             kept = r.cmd.visible_draws()
+            if len(sc.draws) >= 256:  # the next frame counts into the other pair of list lengths
+                color2, depth2 = r.render()
+                if not (np.array_equal(color, color2) and np.array_equal(depth, depth2)):
+                    print("seed %d: the second frame of the command buffer differs from the first" % seed, flush=True)
+                    bad += 1
         finally:
             r.destroy()
         oc, od, _ = oracle.render_scene(sc, threads=8)
