@@ -232,8 +232,6 @@ struct FrameParams {
     DrawDerived* derived;
     const Chunk* vchunks;
     const Chunk* tchunks;
-    Chunk* visible_vchunks;  /* compact != 0: the chunks of the draws this frame found visible, dense, in no particular order; */
-    Chunk* visible_tchunks;  /* their lengths are counters[CTR_VISIBLE + 2 * list_parity + 0 / 1] */
     const TexDesc* textures;
     SVtx* svtx;
     struct SVary* svary;     /* per vertex: the vertex shader's other outputs */
@@ -262,8 +260,6 @@ struct FrameParams {
      * box of vertices lies wholly beyond one of these four planes, the near plane or the far plane has no
      * fragment inside the rectangle (a device that renders one band of a frame skips the other bands' draws) */
     float cull_lo_x, cull_hi_x, cull_lo_y, cull_hi_y;
-    uint32_t compact;        /* 1: the pass has COMPACT_MIN_DRAWS draws or more */
-    uint32_t list_parity;    /* which pair of list lengths this frame uses: alternates between successive frames of the command buffer */
     uint32_t cull_draws;     /* 0: the boxes are stale (vertex data was written after recording), nothing is culled */
     int32_t clamp_x0, clamp_y0, clamp_x1, clamp_y1; /* inclusive pixel rectangle fragments may land in */
     int32_t area_x0, area_y0, area_x1, area_y1;     /* inclusive render area (cleared and stored) */
@@ -283,6 +279,11 @@ struct FrameParams {
     unsigned long long* probe_cycles; /* a build with RND_PROBES: wave-cycles summed per phase of the tile kernel; otherwise null */
     uint32_t probe_kernel_row; /* a build with RND_PROBES: the row of probe_cycles that holds whole-kernel start and end times */
     uint32_t debug_flags;    /* probe masks of a build with RND_PROBES (timing experiments; results are wrong); otherwise unused */
+    /* a pass of many draws (last, so that the arguments every pass reads stay where the kernels' wide scalar loads want them) */
+    Chunk* visible_vchunks;  /* compact != 0: the chunks of the draws this frame found visible, dense, in no particular order; */
+    Chunk* visible_tchunks;  /* their lengths are counters[CTR_VISIBLE + 2 * list_parity + 0 / 1] */
+    uint32_t compact;        /* 1: the pass has COMPACT_MIN_DRAWS draws or more */
+    uint32_t list_parity;    /* which pair of list lengths this frame uses: alternates between successive frames of the command buffer */
 };
 
 

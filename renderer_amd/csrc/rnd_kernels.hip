@@ -433,6 +433,29 @@ __global__ __launch_bounds__(DRAWS_THREADS) void k_draws(VertexArgs args)
     append_chunks(fp.visible_tchunks, &lengths[1], draw, n_t);
 }
 
+/* The same for a pass of few draws with many vertices each (no lists): one WAVE per draw, its lanes sharing out the
+ * matrices' elements and the box's corners -- a tenth of the latency of one lane doing all of it, which is what a pass of
+ * one draw waits for before its vertex kernel starts. */
+__global__ __launch_bounds__(256) void k_draws_by_wave(VertexArgs args)
+{
+    const FrameParams& fp = args.fp;
+    const uint32_t draw = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (draw >= fp.n_draws) return;
+    const DrawStatic& d = fp.draws[draw];
+    float m[16], nm[9];
+    const float mine = wave_matrix_element(args.up, d, d.shader, d.ubo);
+    wave_clip_matrix(mine, m);
+    bool outside = d.vert_count == 0u;
+    if (d.has_bounds != 0u && fp.cull_draws != 0u) outside = outside || draw_is_outside(fp, d, m);
+    DrawDerived& out = fp.derived[draw];
+    if (lane_id() == 0) out.visible = outside ? 0u : 1u;
+    if (outside) return;
+    wave_normal_matrix(d.shader, mine, nm);
+    if (lane_id() < 16u) out.clip_m[lane_id()] = mine;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) if (lane_id() == (uint32_t)i) out.nrm_m[i] = nm[i];
+}
+
 /* Tables that no kernel of the frame writes while this one runs, read through the constant address space: a wave-uniform
  * address there is always a scalar load, also after the kernel's own stores (a kernel that walks a list of chunks has
  * stored the previous chunk's vertices when it reads the next chunk's draw) */
@@ -443,7 +466,7 @@ __device__ __forceinline__ const __attribute__((address_space(4))) T* constant_t
 }
 
 /* One wave, one chunk of 64 vertices of one draw.  PREPARED: k_draws has run. */
-template <bool PREPARED>
+template <bool PREPARED, bool ZERO_COUNTERS>
 __device__ __forceinline__ void vertex_chunk(const VertexArgs& args, Chunk c)
 {
     const FrameParams& fp = args.fp;
@@ -461,6 +484,9 @@ __device__ __forceinline__ void vertex_chunk(const VertexArgs& args, Chunk c)
     } const d = {dk->vb, dk->ubo, dk->stride, dk->off_pos, dk->off_nrm, dk->off_uv, dk->shader, dk->vert_count, dk->svtx_base, dk->has_bounds};
     uint32_t visible = 1u;
     if constexpr (PREPARED) visible = constant_table(fp.derived)[c.draw].visible;
+    /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel
+     * (the first three threads of the grid belong to chunk 0, which every launch has) */
+    if constexpr (ZERO_COUNTERS) if (blockIdx.x == 0 && threadIdx.x < CTR_FRAME_COUNT) fp.counters[threadIdx.x] = 0;
     float m[16], nm[9], mine = 0.0f;
     if (!visible) return;
     const bool cullable = !PREPARED && d.has_bounds != 0u && fp.cull_draws != 0u;
@@ -569,21 +595,21 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
 {
     const FrameParams& fp = args.fp;
     RND_KERNEL_BEGIN(fp, 0);
-    /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel */
-    if (blockIdx.x == 0 && threadIdx.x < CTR_FRAME_COUNT) fp.counters[threadIdx.x] = 0;
     const uint32_t wave = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
     if constexpr (COMPACT) {
+        /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel */
+        if (blockIdx.x == 0 && threadIdx.x < CTR_FRAME_COUNT) fp.counters[threadIdx.x] = 0;
         const uint32_t listed = min(constant_table(fp.counters)[CTR_VISIBLE + 2u * fp.list_parity], fp.n_vchunks);
         const auto* list = constant_table(fp.visible_vchunks);
         for (uint32_t i = wave; i < listed; i += gridDim.x * 4u) {
             const Chunk c = {list[i].draw, list[i].first};
-            vertex_chunk<true>(args, c);
+            vertex_chunk<true, false>(args, c);
         }
     } else {
         if (wave >= fp.n_vchunks) return;
         Chunk c = {0u, wave * 64u}; /* what the chunk table of a one-draw pass holds */
         if (!fp.direct_index) c = fp.vchunks[wave];
-        vertex_chunk<PREPARED>(args, c);
+        vertex_chunk<PREPARED, true>(args, c);
     }
     RND_KERNEL_END(fp, 0u);
 }
@@ -2251,7 +2277,7 @@ void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t
         hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + DRAWS_THREADS - 1) / DRAWS_THREADS), dim3(DRAWS_THREADS), 0, s, args);
         hipLaunchKernelGGL((k_vertex<true, true>), dim3(blocks < list_walk_blocks() ? blocks : list_walk_blocks()), dim3(256), 0, s, args);
     } else if (fp.n_vchunks >= PER_DRAW_KERNEL_MIN_WAVES) {
-        hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + DRAWS_THREADS - 1) / DRAWS_THREADS), dim3(DRAWS_THREADS), 0, s, args);
+        hipLaunchKernelGGL(k_draws_by_wave, dim3((fp.n_draws + 3) / 4), dim3(256), 0, s, args);
         hipLaunchKernelGGL((k_vertex<true, false>), dim3(blocks), dim3(256), 0, s, args);
     } else {
         hipLaunchKernelGGL((k_vertex<false, false>), dim3(blocks), dim3(256), 0, s, args);
