@@ -2066,6 +2066,98 @@ __device__ __forceinline__ void shade_and_store(const FrameParams& fp, const Tab
     store_word(fp.color, pi << 2, pack_color(fp, tb, acc));
 }
 
+/* Several samples per pixel: one shading per distinct owner among a pixel's samples, and the wave's shadings shared out
+ * among its lanes.  A lane first shades its own pixel's first owner.  What is left -- a pixel on an edge has one more owner,
+ * one on a vertex of the mesh up to three more -- is numbered over the wave (a scan of the counts), and lane l of each
+ * further turn takes item 64 (turn - 1) + l: it finds the lane that holds the item (as raster_chunks finds a chunk's
+ * triangle), fetches that lane's pixel and owner, shades, and the holder fetches the colour back.  A wave then runs
+ * 1 + ceil(items / 64) turns of shading instead of as many as its pixel with the most owners has: a mesh of pixel-sized
+ * triangles has a pixel with four owners in almost every wave and 1.9 owners per pixel on average.
+ *
+ * p: the pixel's number in the tile; every lane of the wave calls this (inside: the pixel lies in the render area). */
+template <int S, bool SPEC, typename Tables>
+__device__ __forceinline__ void shade_shared_and_store(const FrameParams& fp, const Tables& tb, LdsLevels pass_levels, const TileCtx& tc,
+                                                       uint32_t p, bool inside, uint32_t pi, const uint32_t* vis)
+{
+    static_assert(S == 4, "a pixel has at most three owners beyond its first");
+    const uint32_t lane = lane_id();
+    /* the distinct owners in the order of their first samples */
+    uint32_t own[S], n = 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) own[k] = VIS_NONE;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        bool fresh = inside && vis[s] != VIS_NONE;
+#pragma unroll
+        for (int q = 0; q < s; ++q) fresh = fresh && vis[q] != vis[s];
+#pragma unroll
+        for (int k = 0; k <= s; ++k) if (fresh && n == (uint32_t)k) own[k] = vis[s];
+        n += fresh ? 1u : 0u;
+    }
+    const int extra = n > 1u ? (int)n - 1 : 0;
+    const int incl = wave_inclusive_scan(extra, 0, [](int a, int b) { return a + b; });
+    const int excl = incl - extra;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int turns = 1 + (total + 63) / 64;
+    float col[S][4];
+#pragma unroll
+    for (int k = 0; k < S; ++k) col[k][0] = col[k][1] = col[k][2] = col[k][3] = 0.0f;
+#pragma unroll 1
+    for (int turn = 0; turn < turns; ++turn) {
+        uint32_t at = p, owner = own[0];
+        bool valid = n >= 1u;
+        const int first_item = (turn - 1) * 64;
+        if (turn > 0) {
+            const int item = first_item + (int)lane;
+            volatile signed char* row = tc.wave_row; /* lanes talk to each other through it: every access is to happen as written */
+            row[lane] = -1;
+            if (extra > 0 && excl >= first_item && excl < first_item + 64) row[excl - first_item] = (signed char)lane;
+            const unsigned long long before = __ballot(extra > 0 && excl <= first_item);
+            const int carried = before ? 63 - __builtin_clzll(before) : 0;
+            const int o = max(wave_inclusive_scan((int)row[lane], -1, [](int a, int b) { return max(a, b); }), carried);
+            const int k = item - __shfl(excl, o); /* which of the holder's further owners */
+            const uint32_t o1 = (uint32_t)__shfl((int)own[1], o), o2 = (uint32_t)__shfl((int)own[2], o), o3 = (uint32_t)__shfl((int)own[3], o);
+            at = (uint32_t)__shfl((int)p, o);
+            owner = k == 0 ? o1 : (k == 1 ? o2 : o3);
+            valid = item < total;
+        }
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (valid)
+            shade_pixel<SPEC>(fp, tb, pass_levels, owner & SLOT_MASK, (owner >> ENTRY_SUB_SHIFT) & 7u, (owner & FLAG_CLIPPED) != 0u,
+                              tc.px0 + (int)(at & (TILE_W - 1)), tc.py0 + (int)(at >> TILE_SHIFT), c);
+        if (turn == 0) {
+            col[0][0] = c[0]; col[0][1] = c[1]; col[0][2] = c[2]; col[0][3] = c[3];
+        } else {
+#pragma unroll
+            for (int kk = 1; kk < S; ++kk) {
+                const int j = excl + (kk - 1) - first_item; /* the lane that shaded this lane's owner kk, if it was this turn */
+                const bool here = kk <= extra && j >= 0 && j < 64;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float got = __shfl(c[q], j & 63);
+                    if (here) col[kk][q] = got;
+                }
+            }
+        }
+    }
+    if (!inside) return;
+    /* no fragment landed on the pixel: the clear colour, encoded once on the host */
+    if (n == 0u) { store_word(fp.color, pi << 2, fp.clear_packed); return; }
+    float smp[S][4];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        smp[s][0] = fp.clear_color[0]; smp[s][1] = fp.clear_color[1]; smp[s][2] = fp.clear_color[2]; smp[s][3] = fp.clear_color[3];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            if ((uint32_t)k < n && vis[s] == own[k]) { smp[s][0] = col[k][0]; smp[s][1] = col[k][1]; smp[s][2] = col[k][2]; smp[s][3] = col[k][3]; }
+        }
+    }
+    float acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = ((smp[0][c] + smp[1][c]) + (smp[2][c] + smp[3][c])) * 0.25f;
+    store_word(fp.color, pi << 2, pack_color(fp, tb, acc));
+}
+
 /* One workgroup per 32x32 tile, in two phases.  Rasterise the tile's triangles into one 64-bit
  * word per sample held in LDS (depth, submission order, fan index; the minimum wins).  Then every
  * thread takes the tile's pixels one row of eight at a time: depth word and owner of each sample
@@ -2164,23 +2256,27 @@ __global__ __launch_bounds__(TILE_THREADS, (S == 1 && (TH == TILE_H || SPEC) ? T
     if (threadIdx.x == 0) fp.tile_count[(size_t)tile * TILE_COUNT_STRIDE] = 0;
     RND_STAMP(fp, stamp, 2); /* waiting for the other waves' rasterisation */
 
+    static_assert(TILE_PIXELS % TILE_THREADS == 0, "every lane of a wave runs the same number of turns of the loop below");
     for (uint32_t p = threadIdx.x; p < TILE_PIXELS; p += TILE_THREADS) {
         const int x = tc.px0 + (int)(p & (TILE_W - 1)), y = tc.py0 + (int)(p >> TILE_SHIFT);
-        if (x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1) continue;
+        const bool inside = !(x < fp.area_x0 || x > fp.area_x1 || y < fp.area_y0 || y > fp.area_y1);
+        if (S == 1 && !inside) continue; /* several samples: the wave shares its shadings out, every lane goes along */
         const uint32_t pi = (uint32_t)y * fp.width + (uint32_t)x; /* a target is at most 8192 x 8192 pixels of 4 samples: byte offsets fit 32 bits */
         uint32_t vis[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+            vis[s] = VIS_NONE;
+            if (!inside) continue;
             const unsigned long long k = keys[p * S + s];
             store_word(fp.depth, (pi * S + s) << 2, fp.depth_test ? (uint32_t)(k >> 40) : fp.clear_d24);
-            vis[s] = VIS_NONE;
             if (k != clear_key) {
                 const uint32_t low = (uint32_t)(k >> 8);
                 const uint32_t fan_clipped = (uint32_t)(k & 15ull) ^ (fp.depth_less ? 0u : 7u); /* the fan index as the rasteriser complemented it */
                 vis[s] = ((fp.depth_less ? low : ~low) & SLOT_MASK) | (fan_clipped << ENTRY_SUB_SHIFT);
             }
         }
-        shade_and_store<S, SPEC>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);
+        if constexpr (S == 1) shade_and_store<S, SPEC>(fp, tb, (LdsLevels)pass_levels, x, y, pi, vis);
+        else shade_shared_and_store<S, SPEC>(fp, tb, (LdsLevels)pass_levels, tc, p, inside, pi, vis);
     }
     RND_STAMP(fp, stamp, 8); /* shading */
     RND_STAMP_END(fp);
