@@ -1069,6 +1069,87 @@ __device__ __forceinline__ void walk_samples(const EdgeSetup<int32_t, S>& es, co
     }
 }
 
+/* What a multisample walk over part of a small triangle's box needs, whichever part it is (the four-sample counterpart of
+ * WalkSetup): the three edge values at the corner of the box's first pixel, their steps per pixel right and down, each
+ * sample's constant per edge (ownership bias folded in), the depth plane and the fragment word's low bits.  Taken once per
+ * triangle by the lane that holds it; a lane that is dealt a chunk of the box fetches these words from that lane and starts
+ * its walk with six multiply-adds, instead of setting the triangle up again for every chunk. */
+template <int S>
+struct SampleWalkSetup {
+    int32_t e0, e1, e2;     /* at the corner of the box's first pixel */
+    int32_t sx0, sx1, sx2;  /* one pixel right */
+    int32_t sy0, sy1, sy2;  /* one pixel down */
+    int32_t o0[S], o1[S], o2[S];
+    float z0, gz1, gz2;
+    uint32_t pay_lo, pay_hi;
+    uint32_t box;           /* bits 0..4 first column in the tile, 5..10 first row, 11..15 width - 1, 16..26 pixels - 1, 30/31 bias of edges 1/2 */
+
+    __device__ __forceinline__ void init(const FrameParams& fp, const TileCtx& tc, const RasterTri& t, int x0, int y0, int w, int area)
+    {
+        EdgeSetup<int32_t, S> es;
+        es.init(fp, t);
+        const int32_t px = x0 * 256, py = y0 * 256;
+        e0 = edge_mul(es.dx0, py - es.ay0) - edge_mul(es.dy0, px - es.ax0);
+        e1 = edge_mul(es.dx1, py - es.ay1) - edge_mul(es.dy1, px - es.ax1);
+        e2 = edge_mul(es.dx2, py - es.ay2) - edge_mul(es.dy2, px - es.ax2);
+        sx0 = -(es.dy0 << 8); sx1 = -(es.dy1 << 8); sx2 = -(es.dy2 << 8);
+        sy0 = es.dx0 << 8; sy1 = es.dx1 << 8; sy2 = es.dx2 << 8;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            o0[s] = edge_mul(es.dx0, (int32_t)c_sample_y4[s]) - edge_mul(es.dy0, (int32_t)c_sample_x4[s]) - es.bias0;
+            o1[s] = edge_mul(es.dx1, (int32_t)c_sample_y4[s]) - edge_mul(es.dy1, (int32_t)c_sample_x4[s]) - es.bias1;
+            o2[s] = edge_mul(es.dx2, (int32_t)c_sample_y4[s]) - edge_mul(es.dy2, (int32_t)c_sample_x4[s]) - es.bias2;
+        }
+        z0 = es.z0; gz1 = es.gz1; gz2 = es.gz2; pay_lo = es.pay_lo; pay_hi = es.pay_hi;
+        box = (uint32_t)(x0 - tc.px0) | ((uint32_t)(y0 - tc.py0) << 5) | ((uint32_t)(w - 1) << 11) | ((uint32_t)(area - 1) << 16) |
+              ((uint32_t)es.bias1 << 30) | ((uint32_t)es.bias2 << 31);
+    }
+
+    __device__ __forceinline__ SampleWalkSetup from_lane(int o) const
+    {
+        SampleWalkSetup u;
+        u.e0 = __shfl(e0, o); u.e1 = __shfl(e1, o); u.e2 = __shfl(e2, o);
+        u.sx0 = __shfl(sx0, o); u.sx1 = __shfl(sx1, o); u.sx2 = __shfl(sx2, o);
+        u.sy0 = __shfl(sy0, o); u.sy1 = __shfl(sy1, o); u.sy2 = __shfl(sy2, o);
+#pragma unroll
+        for (int s = 0; s < S; ++s) { u.o0[s] = __shfl(o0[s], o); u.o1[s] = __shfl(o1[s], o); u.o2[s] = __shfl(o2[s], o); }
+        u.z0 = __shfl(z0, o); u.gz1 = __shfl(gz1, o); u.gz2 = __shfl(gz2, o);
+        u.pay_lo = (uint32_t)__shfl((int)pay_lo, o); u.pay_hi = (uint32_t)__shfl((int)pay_hi, o);
+        u.box = (uint32_t)__shfl((int)box, o);
+        return u;
+    }
+
+    __device__ __forceinline__ int pixels() const { return (int)((box >> 16) & 2047u) + 1; }
+
+    /* pixels k0 .. k1-1 of the box in row order */
+    __device__ __forceinline__ void walk(const TileCtx& tc, int k0, int k1) const
+    {
+        const int w = (int)((box >> 11) & 31u) + 1;
+        const int32_t b1 = (int32_t)((box >> 30) & 1u), b2 = (int32_t)(box >> 31);
+        int row = (int)((float)k0 * __builtin_amdgcn_rcpf((float)w)); /* within one of k0 / w */
+        int col = k0 - row * w;
+        if (col < 0) { --row; col += w; } else if (col >= w) { ++row; col -= w; }
+        int32_t a0 = e0 + __mul24(col, sx0) + __mul24(row, sy0);
+        int32_t a1 = e1 + __mul24(col, sx1) + __mul24(row, sy1);
+        int32_t a2 = e2 + __mul24(col, sx2) + __mul24(row, sy2);
+        const int32_t nl0 = sy0 - __mul24(w - 1, sx0), nl1 = sy1 - __mul24(w - 1, sx1), nl2 = sy2 - __mul24(w - 1, sx2);
+        uint32_t pix = (((box >> 5) & 63u) + (uint32_t)row) * TILE_W + (box & 31u) + (uint32_t)col;
+        EdgeSetup<int32_t, S> es; /* only its depth plane is used */
+        es.z0 = z0; es.gz1 = gz1; es.gz2 = gz2; es.pay_lo = pay_lo; es.pay_hi = pay_hi;
+        for (int i = k0; i < k1; ++i) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int32_t c0 = a0 + o0[s], c1 = a1 + o1[s], c2 = a2 + o2[s];
+                if ((c0 | c1 | c2) >= 0) es.emit(tc, pix * S + s, c1 + b1, c2 + b2);
+            }
+            const bool last = ++col == w;
+            a0 += last ? nl0 : sx0; a1 += last ? nl1 : sx1; a2 += last ? nl2 : sx2;
+            pix += last ? (uint32_t)(TILE_W - w + 1) : 1u;
+            if (last) col = 0;
+        }
+    }
+};
+
 __device__ __forceinline__ bool tri_box_in_tile(const FrameParams& fp, const TileCtx& tc, const RasterTri& t,
                                                 int& x0, int& y0, int& x1, int& y1)
 {
@@ -1190,8 +1271,8 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int identity, Op op)
  * round whatever the mix of box sizes, and nothing is left to the whole-wave path except triangles
  * too large for 32-bit edge products. */
 constexpr int DIRECT_PIXELS = 32; /* measured: 16-pixel chunks balance best, but a wave of boxes up to 32 pixels is quicker walked as it is; the same holds at four samples per pixel */
-constexpr int CHUNK_PIXELS = 16;
-constexpr int CHUNK_STEPS = CHUNK_PIXELS / WALK_ROWS; /* measured: 6 steps +0.4 %, 12 steps +2.3 %, 16 steps +3.9 % on the 4K instances frame */
+constexpr int CHUNK_PIXELS = 8; /* several samples per pixel; measured on the 4K instances frame at four samples: 16 pixels +1.1 %, 24 +6 %, 32 +10 % */
+constexpr int CHUNK_STEPS = 8; /* one sample per pixel: steps of the two-row walk, 16 pixels; measured: 6 steps +0.4 %, 12 steps +2.3 %, 16 steps +3.9 % on the 4K instances frame */
 
 template <int S>
 __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileCtx& tc, bool active, const RasterTri& t,
@@ -1205,8 +1286,9 @@ __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileC
     const int incl = wave_inclusive_scan(n, 0, [](int a, int b) { return a + b; });
     const int excl = incl - n;
     const int total = __builtin_amdgcn_readlane(incl, 63);
-    WalkSetup mine;
+    typename std::conditional<S == 1, WalkSetup, SampleWalkSetup<S>>::type mine;
     if constexpr (S == 1) mine.init(fp, tc, t, x0, y0, active ? w : 1, active ? h : 1);
+    else mine.init(fp, tc, t, x0, y0, active ? w : 1, active ? area : 1);
     for (int base = 0; base < total; base += 64) {
         const int c = base + lane;
         /* owner of chunk c: the last lane that has chunks and whose first chunk number is not above c.  Every such lane
@@ -1219,27 +1301,15 @@ __device__ __forceinline__ void raster_chunks(const FrameParams& fp, const TileC
         const unsigned long long before = __ballot(n > 0 && excl <= base);
         const int carried = before ? 63 - __builtin_clzll(before) : 0;
         const int o = max(wave_inclusive_scan((int)row[lane], -1, [](int a, int b) { return max(a, b); }), carried);
+        const auto u = mine.from_lane(o);
+        const int ofirst = __shfl(excl, o);
+        if (c >= total) continue;
         if constexpr (S == 1) {
-            const WalkSetup u = mine.from_lane(o);
-            const int ofirst = __shfl(excl, o);
-            if (c >= total) continue;
             const int k0 = (c - ofirst) * CHUNK_STEPS, k1 = min(k0 + CHUNK_STEPS, u.steps());
             u.walk(tc, k0, k1);
         } else {
-            RasterTri u;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { u.x[k] = __shfl(t.x[k], o); u.y[k] = __shfl(t.y[k], o); u.z[k] = __shfl(t.z[k], o); }
-            u.payload_lo = (uint32_t)__shfl((int)t.payload_lo, o);
-            u.slot = (uint32_t)__shfl((int)t.slot, o);
-            const int ox0 = __shfl(x0, o), oy0 = __shfl(y0, o), ow = __shfl(w, o), oarea = __shfl(area, o), ofirst = __shfl(excl, o);
-            if (c >= total) continue;
-            const int k0 = (c - ofirst) * CHUNK_PIXELS, k1 = min(k0 + CHUNK_PIXELS, oarea);
-            int row = (int)((float)k0 * __builtin_amdgcn_rcpf((float)ow)); /* within one of k0 / ow */
-            int col = k0 - row * ow;
-            if (col < 0) { --row; col += ow; } else if (col >= ow) { ++row; col -= ow; }
-            EdgeSetup<int32_t, S> es;
-            es.init(fp, u);
-            walk_samples<S>(es, tc, ox0, oy0, ow, k0, k1, row, col);
+            const int k0 = (c - ofirst) * CHUNK_PIXELS, k1 = min(k0 + CHUNK_PIXELS, u.pixels());
+            u.walk(tc, k0, k1);
         }
     }
 }
