@@ -23,10 +23,16 @@ constexpr int TILE_PIXELS_MAX = TILE_W * TILE_H_TALL;
 constexpr int TILE_THREADS = TILE_THREADS_N; /* a multiple of 64; a build option: 128 gains 6 % at 4K and costs 38 % at 720p, 192 and 320 lose everywhere */
 constexpr int CHUNK = 64;            /* primitives (or vertices) handled by one wave */
 constexpr int MAX_TILES_PER_PRIM = 16; /* primitives touching more tiles go to the pass-wide list */
-/* Words 0..2 are zeroed by each frame's vertex kernel.  Words 3..6 are the lengths of the lists of visible chunks
+/* Words 0..2 are zeroed by each frame's vertex kernel.  Four more words are the lengths of the lists of visible chunks
  * (vertex chunks, primitive chunks) that the per-draw kernel of a pass of many draws builds: two pairs, used by
- * alternate frames, so that a frame's per-draw kernel can zero the pair the next frame will count into. */
-enum : uint32_t { CTR_LARGE = 0, CTR_CLIP_TRIS = 1, CTR_OVERFLOW = 2, CTR_FRAME_COUNT = 3, CTR_VISIBLE = 3, CTR_COUNT = 7 };
+ * alternate frames, so that a frame's per-draw kernel can zero the pair the next frame will count into -- each in a
+ * 128-byte line of its own (visible_length), so that the atomics on the two lists do not queue behind one another. */
+enum : uint32_t { CTR_LARGE = 0, CTR_CLIP_TRIS = 1, CTR_OVERFLOW = 2, CTR_FRAME_COUNT = 3, CTR_COUNT = 160 };
+/* word of the length of list `which` (0: vertex chunks, 1: primitive chunks) of the frames of parity `parity` */
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t visible_length(uint32_t parity, uint32_t which) { return 32u + 32u * (2u * parity + which); }
 /* a pass of at least this many draws gets the per-draw kernel, which leaves the chunks of the draws it found visible in
  * two dense lists; the vertex and setup kernels then run over those with a fixed grid, and a culled draw costs them nothing */
 constexpr uint32_t COMPACT_MIN_DRAWS = 256;
@@ -281,7 +287,7 @@ struct FrameParams {
     uint32_t debug_flags;    /* probe masks of a build with RND_PROBES (timing experiments; results are wrong); otherwise unused */
     /* a pass of many draws (last, so that the arguments every pass reads stay where the kernels' wide scalar loads want them) */
     Chunk* visible_vchunks;  /* compact != 0: the chunks of the draws this frame found visible, dense, in no particular order; */
-    Chunk* visible_tchunks;  /* their lengths are counters[CTR_VISIBLE + 2 * list_parity + 0 / 1] */
+    Chunk* visible_tchunks;  /* their lengths are counters[visible_length(list_parity, 0 / 1)] */
     uint32_t compact;        /* 1: the pass has COMPACT_MIN_DRAWS draws or more */
     uint32_t list_parity;    /* which pair of list lengths this frame uses: alternates between successive frames of the command buffer */
 };
@@ -299,7 +305,7 @@ constexpr uint32_t NA_CLIP_TRI_CAPACITY = 16384;
 struct NoAllocLayout {
     static constexpr size_t draw = 0;                                                     /* DrawStatic[1] */
     static constexpr size_t derived = draw + 256;                                         /* DrawDerived[1] */
-    static constexpr size_t counters = derived + 256;                                     /* CTR_COUNT words */
+    static constexpr size_t counters = derived + 256;                                     /* CTR_FRAME_COUNT words (a pass of one draw keeps no lists of visible chunks) */
     static constexpr size_t ubo = counters + 256;                                         /* where the uniform block would live (320 bytes) */
     static constexpr size_t tile_count = ubo + 512;
     static constexpr size_t svtx = tile_count + (size_t)NA_MAX_TILES * TILE_COUNT_STRIDE * 4;

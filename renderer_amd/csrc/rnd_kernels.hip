@@ -326,111 +326,154 @@ __device__ __forceinline__ bool draw_is_outside(const FrameParams& fp, const Dra
     return outside;
 }
 
-/* by one lane, corner after corner */
-__device__ __forceinline__ bool draw_is_outside_lane(const FrameParams& fp, const DrawStatic& d, const float* m)
-{
-    uint32_t all = 63u;
-    for (uint32_t corner = 0; corner < 8u; ++corner) all &= corner_beyond(fp, d, m, corner);
-    return all != 0u;
-}
-
 /* ... and a pass of few draws with many vertices: every vertex wave would build its draw's matrices again (two thirds of
  * such a wave's vector instructions), which for some thousand waves is more than the extra launch costs */
 constexpr uint32_t PER_DRAW_KERNEL_MIN_WAVES = 2048;
 
-/* `count` chunks of 64 (vertices or primitives) of this lane's draw join the dense list: the wave takes one range of
- * the list for all its draws, with one atomic, and each lane writes its draw's chunks -- a draw of very many chunks
- * has them written by the whole wave. */
-__device__ __forceinline__ void append_chunks(Chunk* list, uint32_t* length, uint32_t draw, uint32_t count)
+/* Scans over the wave by data-parallel-primitive moves (row shifts inside each 16-lane row, then the rows' last
+ * lanes broadcast to the rows after them): six vector instructions, where shuffles through the LDS crossbar take a
+ * round trip per step. */
+template <typename Op>
+__device__ __forceinline__ int wave_inclusive_scan(int v, int identity, Op op)
 {
-    const uint32_t lane = lane_id();
-    uint32_t incl = count;
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 into rows 1 and 3 */
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
+/* `count_v` chunks of 64 vertices and `count_t` chunks of 64 primitives of this lane's draw join the two dense lists.
+ * The workgroup takes one range of each list for all its draws with ONE atomic per list (some thousand atomics a frame on
+ * one address cost ten nanoseconds each, which for a pass of 40 000 draws was most of the kernel when every wave issued its
+ * own): the waves scan their lanes' counts, leave their totals in LDS, thread 0 adds the workgroup's total to the list's
+ * length and leaves every wave its first place.  Each lane then writes its draw's chunks; a draw of very many chunks has
+ * them written by its whole wave. */
+constexpr uint32_t DRAWS_THREADS = 512;
+__device__ __forceinline__ void append_chunks(const FrameParams& fp, uint32_t draw, uint32_t count_v, uint32_t count_t)
+{
+    __shared__ uint32_t wave_first[2][DRAWS_THREADS / 64];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t count[2] = {count_v, count_t}, incl[2];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t below = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= (uint32_t)d) incl += below;
+    for (int which = 0; which < 2; ++which) {
+        incl[which] = (uint32_t)wave_inclusive_scan((int)count[which], 0, [](int x, int y) { return x + y; });
+        if (lane == 63u) wave_first[which][wave] = incl[which];
     }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    if (!total) return;
-    uint32_t base = 0u;
-    if (lane == 0u) base = atomicAdd(length, total);
-    base = wave_uniform(base);
-    const uint32_t at = base + incl - count;
-    constexpr uint32_t FEW = 8u;
-    if (count <= FEW)
-        for (uint32_t j = 0; j < count; ++j) list[at + j] = Chunk{draw, j * 64u};
-    uint64_t many = __ballot(count > FEW);
-    while (many) {
-        const int l = __ffsll((unsigned long long)many) - 1;
-        many &= many - 1ull;
-        const uint32_t n = (uint32_t)__shfl((int)count, l), first = (uint32_t)__shfl((int)at, l), dr = (uint32_t)__shfl((int)draw, l);
-        for (uint32_t j = lane; j < n; j += 64u) list[first + j] = Chunk{dr, j * 64u};
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        const uint32_t which = threadIdx.x;
+        uint32_t total = 0u;
+        for (uint32_t w = 0; w < blockDim.x / 64u; ++w) total += wave_first[which][w];
+        uint32_t first = total ? atomicAdd(&fp.counters[visible_length(fp.list_parity, which)], total) : 0u;
+        for (uint32_t w = 0; w < blockDim.x / 64u; ++w) { const uint32_t t = wave_first[which][w]; wave_first[which][w] = first; first += t; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        Chunk* list = which ? fp.visible_tchunks : fp.visible_vchunks;
+        const uint32_t n = count[which];
+        const uint32_t at = wave_first[which][wave] + incl[which] - n;
+        constexpr uint32_t FEW = 8u;
+        if (n <= FEW)
+            for (uint32_t j = 0; j < n; ++j) list[at + j] = Chunk{draw, j * 64u};
+        uint64_t many = __ballot(n > FEW);
+        while (many) {
+            const int l = __ffsll((unsigned long long)many) - 1;
+            many &= many - 1ull;
+            const uint32_t m = (uint32_t)__shfl((int)n, l), first = (uint32_t)__shfl((int)at, l), dr = (uint32_t)__shfl((int)draw, l);
+            for (uint32_t j = lane; j < m; j += 64u) list[first + j] = Chunk{dr, j * 64u};
+        }
     }
 }
 
-/* A pass of many small draws, or of many vertex waves: one LANE per draw builds what the draw's vertex waves would each
- * build again (a draw of 162 vertices has three of them, and the matrices are most of such a wave's instructions) -- the
- * two matrices and the verdict on the draw's box.  The vertex kernel then starts from scalar loads.  In a pass of many
- * draws the chunks of the visible ones also go to two dense lists, which the vertex and setup kernels walk: a culled draw
- * costs them nothing (a device that renders one band of a frame culls most of the pass). */
-constexpr uint32_t DRAWS_THREADS = 64; /* one wave per workgroup: a pass of 10 000 draws is then spread over 157 CUs instead of 40 */
+/* A pass of many small draws: EIGHT LANES per draw build what the draw's vertex waves would each build again (a draw of
+ * 162 vertices has three of them, and the matrices are most of such a wave's instructions) -- the two matrices and the
+ * verdict on the draw's box.  Lane r of a draw's eight computes elements r and r + 8 of the clip matrix and one (lane 0: two)
+ * of the nine elements of model * transform that the normal matrix is made of, every load of a lane requested at once; the
+ * eight exchange their elements, lane r takes corner r of the box, and the verdicts are combined over the eight.  The
+ * chunks of the visible draws then go to two dense lists, which the vertex and setup kernels walk: a culled draw costs
+ * them nothing (a device that renders one band of a frame culls most of the pass). */
+constexpr uint32_t DRAW_LANES = 8;
+constexpr uint32_t DRAWS_PER_BLOCK = DRAWS_THREADS / DRAW_LANES;
+
+/* element k of A * transform with every operand requested before the first is used (the chain of matrix_element) */
+__device__ __forceinline__ float matrix_element_at_once(const UniformPatch& up, const DrawStatic& d, int shader, const float* a, uint32_t k)
+{
+    const uint32_t row = k & 3u, col = k >> 2;
+    if (shader == 0) return uniform_read_both(up, a + k);
+    const float a0 = uniform_read_both(up, a + 0 * 4 + row), a1 = uniform_read_both(up, a + 1 * 4 + row),
+                a2 = uniform_read_both(up, a + 2 * 4 + row), a3 = uniform_read_both(up, a + 3 * 4 + row);
+    const float* b = d.push + 4 + col * 4;
+    const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    float acc = a0 * b0;
+    acc = fma32(a1, b1, acc);
+    acc = fma32(a2, b2, acc);
+    acc = fma32(a3, b3, acc);
+    return acc;
+}
+
 __global__ __launch_bounds__(DRAWS_THREADS) void k_draws(VertexArgs args)
 {
     const FrameParams& fp = args.fp;
-    const uint32_t draw = blockIdx.x * DRAWS_THREADS + threadIdx.x;
-    uint32_t* lengths = fp.counters + CTR_VISIBLE + 2u * fp.list_parity;
+    const uint32_t r = threadIdx.x & (DRAW_LANES - 1u);
+    const uint32_t draw = blockIdx.x * DRAWS_PER_BLOCK + threadIdx.x / DRAW_LANES;
     /* the pair of lengths the previous frame counted into is the next frame's: that frame's kernels have all finished */
-    if (fp.compact && blockIdx.x == 0u && threadIdx.x < 2u) fp.counters[CTR_VISIBLE + 2u * (fp.list_parity ^ 1u) + threadIdx.x] = 0u;
+    if (fp.compact && blockIdx.x == 0u && threadIdx.x < 2u) fp.counters[visible_length(fp.list_parity ^ 1u, threadIdx.x)] = 0u;
+    const bool live = draw < fp.n_draws;
+    const DrawStatic& d = fp.draws[live ? draw : 0u]; /* the lanes of a draw past the end go along (the exchanges want every lane) */
+    const int shader = d.shader;
+    const float* ubo = d.ubo;
+    /* the nine elements of model * transform that matter, in the order the lanes take them: lane r has element
+     * r + r / 3 (0 1 2 4 5 6 8 9), lane 0 element 10 as well */
+    const uint32_t mine_of_model = r + r / 3u;
+    const float c_lo = matrix_element_at_once(args.up, d, shader, ubo + 64, r);
+    const float c_hi = matrix_element_at_once(args.up, d, shader, ubo + 64, r + 8u);
+    float t_a = 0.0f, t_b = 0.0f;
+    if (shader != 0) {
+        t_a = matrix_element_at_once(args.up, d, shader, ubo + 48, mine_of_model);
+        if (r == 0u) t_b = matrix_element_at_once(args.up, d, shader, ubo + 48, 10u);
+    }
+    float m[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = __shfl(c_lo, k, DRAW_LANES); m[k + 8] = __shfl(c_hi, k, DRAW_LANES); }
+    uint32_t beyond = corner_beyond(fp, d, m, r);
+    beyond &= (uint32_t)__shfl_xor((int)beyond, 1, DRAW_LANES);
+    beyond &= (uint32_t)__shfl_xor((int)beyond, 2, DRAW_LANES);
+    beyond &= (uint32_t)__shfl_xor((int)beyond, 4, DRAW_LANES);
+    bool outside = !live || d.vert_count == 0u;
+    if (d.has_bounds != 0u && fp.cull_draws != 0u) outside = outside || beyond != 0u;
+    float mt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mt[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mt[j + j / 3] = __shfl(t_a, j, DRAW_LANES);
+    mt[10] = __shfl(t_b, 0, DRAW_LANES);
+    float nm[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nm[i] = 0.0f;
+    if (shader != 0) normal_matrix(mt, nm);
     uint32_t n_v = 0u, n_t = 0u;
-    if (draw < fp.n_draws) {
-        const DrawStatic& d = fp.draws[draw];
-        const int shader = d.shader;
-        const float* ubo = d.ubo;
-        /* everything the lane reads, requested at once: mvp, the model matrix's three rows, the draw's transform */
-        float mvp[16], model[16], tr[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mvp[k] = uniform_read_both(args.up, ubo + 64 + k);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) model[k] = (k & 3) < 3 && shader != 0 ? uniform_read_both(args.up, ubo + 48 + k) : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tr[k] = d.push[4 + k];
-        /* element k = row + 4 * col of A * transform: the four-term chain of matrix_element */
-        auto product = [&tr](const float* a, int k) -> float {
-            const int row = k & 3, col = k >> 2;
-            float acc = a[0 * 4 + row] * tr[col * 4 + 0];
-            acc = fma32(a[1 * 4 + row], tr[col * 4 + 1], acc);
-            acc = fma32(a[2 * 4 + row], tr[col * 4 + 2], acc);
-            acc = fma32(a[3 * 4 + row], tr[col * 4 + 3], acc);
-            return acc;
-        };
-        float m[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) m[k] = shader == 0 ? mvp[k] : product(mvp, k);
-        bool outside = d.vert_count == 0u;
-        if (d.has_bounds != 0u && fp.cull_draws != 0u) outside = outside || draw_is_outside_lane(fp, d, m);
+    if (live) {
         DrawDerived& out = fp.derived[draw];
-        out.visible = outside ? 0u : 1u;
+        if (r == 0u) out.visible = outside ? 0u : 1u;
         if (!outside) {
-            float nm[9];
+            out.clip_m[r] = c_lo; out.clip_m[r + 8u] = c_hi;
+            float mine = nm[0];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) nm[i] = 0.0f;
-            if (shader != 0) {
-                float mt[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) mt[k] = (k & 3) < 3 && k < 12 ? product(model, k) : 0.0f;
-                normal_matrix(mt, nm);
+            for (int i = 1; i < 8; ++i) if (r == (uint32_t)i) mine = nm[i];
+            out.nrm_m[r] = mine;
+            if (r == 0u) {
+                out.nrm_m[8] = nm[8];
+                n_v = (d.vert_count + 63u) / 64u;
+                n_t = (d.tri_count + 63u) / 64u;
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) out.clip_m[i] = m[i];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) out.nrm_m[i] = nm[i];
-            n_v = (d.vert_count + 63u) / 64u;
-            n_t = (d.tri_count + 63u) / 64u;
         }
     }
     if (!fp.compact) return;
-    append_chunks(fp.visible_vchunks, &lengths[0], draw, n_v);
-    append_chunks(fp.visible_tchunks, &lengths[1], draw, n_t);
+    append_chunks(fp, draw, n_v, n_t);
 }
 
 /* The same for a pass of few draws with many vertices each (no lists): one WAVE per draw, its lanes sharing out the
@@ -599,7 +642,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs args)
     if constexpr (COMPACT) {
         /* the list counters of the previous frame were last read by its tile kernel; binning starts after this kernel */
         if (blockIdx.x == 0 && threadIdx.x < CTR_FRAME_COUNT) fp.counters[threadIdx.x] = 0;
-        const uint32_t listed = min(constant_table(fp.counters)[CTR_VISIBLE + 2u * fp.list_parity], fp.n_vchunks);
+        const uint32_t listed = min(constant_table(fp.counters)[visible_length(fp.list_parity, 0u)], fp.n_vchunks);
         const auto* list = constant_table(fp.visible_vchunks);
         for (uint32_t i = wave; i < listed; i += gridDim.x * 4u) {
             const Chunk c = {list[i].draw, list[i].first};
@@ -838,7 +881,7 @@ __global__ __launch_bounds__(256, 8) void k_setup(FrameParams fp)
     __shared__ float clip_lds[4][CLIP_LDS_FLOATS];
     RND_KERNEL_BEGIN(fp, 1);
     if constexpr (COMPACT) {
-        const uint32_t listed = min(constant_table(fp.counters)[CTR_VISIBLE + 2u * fp.list_parity + 1u], fp.n_tchunks);
+        const uint32_t listed = min(constant_table(fp.counters)[visible_length(fp.list_parity, 1u)], fp.n_tchunks);
         const auto* list = constant_table(fp.visible_tchunks);
         for (uint32_t i = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6)); i < listed; i += gridDim.x * 4u) {
             const Chunk c = {wave_uniform(list[i].draw), wave_uniform(list[i].first)};
@@ -1242,21 +1285,6 @@ __device__ __forceinline__ bool load_raster_tri(const FrameParams& fp, const Til
     t.x[2] = c.xf >> 8; t.y[2] = c.y; t.z[2] = c.z;
     t.payload_lo = 0;
     return true;
-}
-
-/* Scans over the wave by data-parallel-primitive moves (row shifts inside each 16-lane row, then the rows' last
- * lanes broadcast to the rows after them): six vector instructions, where shuffles through the LDS crossbar take a
- * round trip per step. */
-template <typename Op>
-__device__ __forceinline__ int wave_inclusive_scan(int v, int identity, Op op)
-{
-    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */
-    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */
-    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */
-    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */
-    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 into rows 1 and 3 */
-    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 into rows 2 and 3 */
-    return v;
 }
 
 /* Who walks a triangle's box.
@@ -2402,7 +2430,7 @@ __global__ __launch_bounds__(256) void k_noalloc_begin(DrawStatic d, uint8_t* ba
     uint32_t* derived = reinterpret_cast<uint32_t*>(base + NoAllocLayout::derived);
     if (threadIdx.x < sizeof(DrawDerived) / 4) derived[threadIdx.x] = 0u;
     uint32_t* counters = reinterpret_cast<uint32_t*>(base + NoAllocLayout::counters);
-    if (threadIdx.x < CTR_COUNT) counters[threadIdx.x] = 0u;
+    if (threadIdx.x < CTR_FRAME_COUNT) counters[threadIdx.x] = 0u;
     uint32_t* tile_count = reinterpret_cast<uint32_t*>(base + NoAllocLayout::tile_count);
     for (uint32_t t = threadIdx.x; t < n_tiles; t += blockDim.x) tile_count[(size_t)t * TILE_COUNT_STRIDE] = 0u;
 }
@@ -2440,7 +2468,7 @@ void launch_vertex(const FrameParams& fp, const UniformPatch& patch, hipStream_t
     VertexArgs args;
     args.fp = fp; args.up = patch;
     if (fp.compact) {
-        hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + DRAWS_THREADS - 1) / DRAWS_THREADS), dim3(DRAWS_THREADS), 0, s, args);
+        hipLaunchKernelGGL(k_draws, dim3((fp.n_draws + DRAWS_PER_BLOCK - 1) / DRAWS_PER_BLOCK), dim3(DRAWS_THREADS), 0, s, args);
         hipLaunchKernelGGL((k_vertex<true, true>), dim3(blocks < list_walk_blocks() ? blocks : list_walk_blocks()), dim3(256), 0, s, args);
     } else if (fp.n_vchunks >= PER_DRAW_KERNEL_MIN_WAVES) {
         hipLaunchKernelGGL(k_draws_by_wave, dim3((fp.n_draws + 3) / 4), dim3(256), 0, s, args);
