@@ -601,6 +601,41 @@ def test_lists_of_visible_chunks(device, oracle):
     assert np.array_equal(acc_c, full_c) and np.array_equal(acc_d, full_d)
 
 
+@pytest.mark.parametrize("shader", [scenes.SHADER_TEST_KTX, scenes.SHADER_PUSH_CONSTANTS])
+def test_four_samples_pixels_with_many_owners(device, oracle, shader):
+    """Four samples per pixel where pixels have two, three and four owners: fans of thin triangles whose hubs lie inside
+    pixels, some of the hubs in every quarter of a tile, all over a background quad, in a render area that cuts tiles
+    (lanes outside the area go along with the wave's exchange of shadings, with nothing to shade).  Each frame against
+    the oracle."""
+    width, height = 150, 101
+    rng = np.random.RandomState(11)
+    tris = [[(2.0, 3.0, 0.9), (148.0, 2.0, 0.9), (3.0, 99.0, 0.9)], [(148.0, 2.0, 0.9), (147.0, 99.5, 0.9), (3.0, 99.0, 0.9)]]
+    for _ in range(40):
+        hx, hy = float(rng.uniform(5, 145)), float(rng.uniform(5, 96))
+        spokes = int(rng.randint(5, 14))
+        radius = float(rng.uniform(1.5, 9.0))
+        z = float(rng.uniform(0.1, 0.8))
+        first = float(rng.uniform(0, 6.28))
+        ring = [(hx + radius * np.cos(first + 6.2831853 * k / spokes), hy + radius * np.sin(first + 6.2831853 * k / spokes)) for k in range(spokes)]
+        for k in range(spokes):
+            a, b = ring[k], ring[(k + 1) % spokes]
+            tris.append([(hx, hy, z), (float(b[0]), float(b[1]), z + 0.01 * k), (float(a[0]), float(a[1]), z)])
+    tex = scenes._texture(scenes.checker_texture(64, 5)) if shader == scenes.SHADER_TEST_KTX else None
+    sc = helpers.window_triangles(width, height, tris, shader=shader, samples=4, texture=tex, pipeline_kw=dict(cull_mode=0))
+    check(sc, device, oracle)
+    sc.area = (7, 5, 130, 83)
+    sc.scissor = (20, 9, 100, 70)
+    r = SceneRunner(sc, device)
+    try:
+        color, depth = r.render()
+    finally:
+        r.destroy()
+    oc, od, _ = oracle.render_scene(sc, threads=8)
+    ax, ay, aw, ah = sc.area
+    sl = (slice(ay, ay + ah), slice(ax, ax + aw))
+    assert np.array_equal(depth[sl], od[sl]) and np.array_equal(color[sl], oc[sl])
+
+
 def test_resubmission_is_idempotent(device):
     sc = helpers.soup_scene(200, 150, 2000, 77, depth_levels=2, n_draws=7)
     r = SceneRunner(sc, device)
