@@ -636,6 +636,25 @@ def test_four_samples_pixels_with_many_owners(device, oracle, shader):
     assert np.array_equal(depth[sl], od[sl]) and np.array_equal(color[sl], oc[sl])
 
 
+@pytest.mark.parametrize("size", [(8192, 8192, 1), (8192, 2048, 4)])
+def test_largest_target(device, oracle, size):
+    """The largest extent a target may have, 8192 pixels (256 columns of tiles, the last value a tile box's byte holds):
+    triangles in the far corners, one across the whole target, a soup between them; against the oracle."""
+    width, height, samples = size
+    rng = np.random.RandomState(5)
+    w, h = float(width), float(height)
+    tris = [[(1.0, 1.0, 0.8), (w - 1.5, 2.0, 0.8), (2.0, h - 1.25, 0.8)],
+            [(w - 40.0, h - 40.0, 0.3), (w - 0.5, h - 30.0, 0.3), (w - 20.0, h - 0.5, 0.3)],
+            [(w - 33.0, 0.5, 0.2), (w - 0.25, 0.75, 0.2), (w - 0.5, 31.0, 0.2)],
+            [(0.5, h - 31.0, 0.25), (30.0, h - 0.5, 0.25), (0.25, h - 0.25, 0.25)]]
+    for _ in range(300):
+        cx, cy, e = float(rng.uniform(0, w)), float(rng.uniform(0, h)), float(np.exp(rng.uniform(np.log(2.0), np.log(900.0))))
+        z = float(rng.uniform(0.05, 0.95))
+        tris.append([(cx + float(rng.uniform(-e, e)), cy + float(rng.uniform(-e, e)), z) for _ in range(3)])
+    sc = helpers.window_triangles(width, height, tris, samples=samples, pipeline_kw=dict(cull_mode=0))
+    check(sc, device, oracle, threads=16)
+
+
 def test_resubmission_is_idempotent(device):
     sc = helpers.soup_scene(200, 150, 2000, 77, depth_levels=2, n_draws=7)
     r = SceneRunner(sc, device)
