@@ -198,6 +198,30 @@ def test_npot_texture_and_mip_chain(device, oracle):
             gtex.destroy()
 
 
+@pytest.mark.parametrize("shape", [(16384, 2), (3, 16384)])
+def test_texture_of_the_largest_extent(device, oracle, shape):
+    """A side of 16 384 texels, the limit.  Generated mips: the reference's count, one short of a full chain (tools.cpp:514),
+    so 14 levels, equal to the oracle's level by level.  Given levels: the full chain of 15, the most a texture holds.
+    Either way a frame that samples it (minified by thousands along the long side, so the last levels are read) is the
+    oracle's."""
+    rng = np.random.RandomState(9)
+    t = rng.randint(0, 256, size=(shape[1], shape[0], 4)).astype(np.uint8)
+    gtex = api.Texture(device, t, fmt=43, gen_mips=True)
+    levels = oracle.mip_chain(t, True, srgb=True)
+    assert gtex.level_count == len(levels) == 14
+    for l, ref in enumerate(levels):
+        assert np.array_equal(gtex.read_level(l), ref), "level %d" % l
+    gtex.destroy()
+    full = list(levels) + [rng.randint(0, 256, size=(1, 1, 4)).astype(np.uint8)]
+    for tex_dict in (dict(texels=t, gen_mips=True, filtering=1, tiled=False, fmt=43),
+                     dict(texels=t, levels=full, gen_mips=False, filtering=1, tiled=False, fmt=43)):
+        sc = helpers.perspective_soup(160, 120, 120, 31, near_cross=False, shader=scenes.SHADER_TEST_KTX, texture=tex_dict,
+                                      pipeline_kw=dict(cull_mode=0))
+        check(sc, device, oracle)
+    with pytest.raises(api.RendererError):
+        api.Texture(device, t, fmt=43, levels=full + [full[-1]])  # sixteen levels
+
+
 def test_texture_channel_expansion(device, oracle):
     """1-, 2- and 3-channel uploads take the reference's view swizzles (tools.cpp:474-509)."""
     rgb = scenes.checker_texture(32, 5)[..., :3].copy()
