@@ -679,6 +679,28 @@ def test_largest_target(device, oracle, size):
     check(sc, device, oracle, threads=16)
 
 
+@pytest.mark.parametrize("samples", [1, 4])
+def test_a_tile_with_more_triangles_than_its_list_holds(device, oracle, samples):
+    """40 000 small triangles inside one tile (and a few hundred over the rest of a small target): a tile's list holds at
+    most 16 384 entries, the rest spill to the pass-wide list, which every tile scans for entries of its own.  The frame is
+    the oracle's all the same, and no overflow is reported."""
+    rng = np.random.RandomState(21)
+    width, height = 96, 70
+    n = 40000
+    cx, cy = rng.uniform(33.0, 62.0, size=n), rng.uniform(33.0, 62.0, size=n)  # tile (1, 1)
+    tris = []
+    for k in range(n):
+        e = float(rng.uniform(0.4, 3.0))
+        z = float(rng.randint(1, 64)) / 64.0
+        tris.append([(float(cx[k] + rng.uniform(-e, e)), float(cy[k] + rng.uniform(-e, e)), z) for _ in range(3)])
+    for _ in range(300):
+        x, y, e = float(rng.uniform(0, width)), float(rng.uniform(0, height)), float(rng.uniform(1.0, 20.0))
+        tris.append([(x + float(rng.uniform(-e, e)), y + float(rng.uniform(-e, e)), float(rng.uniform(0.1, 0.9))) for _ in range(3)])
+    sc = helpers.window_triangles(width, height, tris, samples=samples, pipeline_kw=dict(cull_mode=0))
+    check(sc, device, oracle)
+    device.wait_idle()  # an overflow of the lists would be reported here
+
+
 def test_resubmission_is_idempotent(device):
     sc = helpers.soup_scene(200, 150, 2000, 77, depth_levels=2, n_draws=7)
     r = SceneRunner(sc, device)
